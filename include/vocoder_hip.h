@@ -1,0 +1,167 @@
+/*
+ * vocoder_hip.h -- C ABI of the MI355X (gfx950) phase-vocoder engine.
+ *
+ * This is the drop-in boundary for the STFT round-trip path of tilk/vocoder.
+ * In the reference that boundary is the `vector-fftw` binding
+ * (Numeric.FFT.Vector.Invertible / .Plan, imported at vocoder/src/Vocoder.hs:49-50);
+ * here it is widened to the whole per-frame / per-stage arithmetic of
+ * vocoder/src/Vocoder.hs so that a batch of frames and channels crosses the
+ * FFI once.  Every entry point cites the reference definition it replaces
+ * (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, int32_t status.  0 = VOC_OK, negative = error;
+ *     voc_strerror() maps a status to text.  Nothing throws across the boundary.
+ *   - all sample / spectrum data is IEEE double, laid out planar
+ *     [channel][frame][bin or sample], bin / sample fastest.  A complex value is
+ *     {re, im} (16 bytes), the layout of Haskell's `Storable (Complex Double)`.
+ *   - N = FFT frame length (vocFrameLength), W = window / input frame length
+ *     (vocInputFrameLength, W <= N), H = hop (vocHopSize), K = N/2+1
+ *     (vocFreqFrameLength).  This build supports N = 2^m, 8 <= N <= 16384.
+ *   - the caller owns every buffer; the library owns only the opaque voc_ctx.
+ *   - entry points without a `_dev` suffix take HOST pointers and copy through
+ *     device memory they allocate; `_dev` entry points take DEVICE pointers and
+ *     a HIP stream (hipStream_t passed as void*, NULL = the default stream) and
+ *     return after enqueueing.
+ *   - a context may be used from any thread; calls on one context serialise on
+ *     an internal mutex (the reference leaves this open: Vocoder.hs:98).
+ */
+#ifndef VOCODER_HIP_H
+#define VOCODER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct voc_ctx voc_ctx;
+
+enum {
+    VOC_OK = 0,
+    VOC_ERR_INVALID = -1,     /* NULL pointer, negative count, W > N (Vocoder.hs:132), H < 1 */
+    VOC_ERR_UNSUPPORTED = -2, /* frame length not a supported power of two, unknown precision */
+    VOC_ERR_HIP = -3,         /* a HIP runtime call failed; see voc_last_hip_error() */
+    VOC_ERR_NOMEM = -4,       /* device or host allocation failed */
+    VOC_ERR_SIZE = -5,        /* buffer / workspace too small, size mismatch (vector-fftw `execute`) */
+    VOC_ERR_NO_DEVICE = -6    /* no usable GPU */
+};
+
+enum { VOC_PRECISION_F64 = 0 };
+
+const char *voc_strerror(int32_t status);
+/* Text of the last failing HIP call made through this context (empty if none). */
+const char *voc_last_hip_error(const voc_ctx *ctx);
+
+/* ---- lifecycle ------------------------------------------------------------------
+ * voc_ctx_create   replaces  vocoderParams len hop window           Vocoder.hs:114-115
+ *                  (and the two `plan dftR2C / dftC2R len` it makes: Vocoder.hs:115)
+ * accessors        replace   vocFrameLength / vocInputFrameLength /
+ *                            vocFreqFrameLength / vocHopSize / vocWindow   Vocoder.hs:95-111
+ * voc_volume_coeff replaces  volumeCoeff                             Vocoder.hs:209-210
+ */
+int32_t voc_ctx_create(int32_t frame_length, int32_t hop, const double *window, int32_t window_length,
+                       int32_t device, int32_t precision, voc_ctx **out);
+int32_t voc_ctx_destroy(voc_ctx *ctx);
+int32_t voc_frame_length(const voc_ctx *ctx);       /* N */
+int32_t voc_input_frame_length(const voc_ctx *ctx); /* W */
+int32_t voc_freq_frame_length(const voc_ctx *ctx);  /* K */
+int32_t voc_hop_size(const voc_ctx *ctx);           /* H */
+int32_t voc_window(const voc_ctx *ctx, double *out /* [W] */);
+double voc_volume_coeff(const voc_ctx *ctx);
+
+/* ---- FFT-compatible layer ---------------------------------------------------------
+ * voc_r2c / voc_c2r replace `FFT.execute` on the two plans          Vocoder.hs:145,196
+ *   r2c: B x N reals -> B x K complex, unnormalised, DC / Nyquist imaginary parts +0
+ *   c2r: B x K complex -> B x N reals, multiplied by 1/N, DC / Nyquist imaginary parts ignored
+ * voc_do_fft  replaces doFFT  (window, symmetric zero pad, rewind, R2C)   Vocoder.hs:143-145
+ * voc_do_ifft replaces doIFFT (C2R, rewind, cutCenter, window)            Vocoder.hs:194-196
+ */
+int32_t voc_r2c(voc_ctx *ctx, const double *in, double *out, int64_t batch);
+int32_t voc_c2r(voc_ctx *ctx, const double *in, double *out, int64_t batch);
+int32_t voc_do_fft(voc_ctx *ctx, const double *frames /* [B][W] */, double *spec /* [B][K] complex */, int64_t batch);
+int32_t voc_do_ifft(voc_ctx *ctx, const double *spec /* [B][K] complex */, double *frames /* [B][W] */, int64_t batch);
+
+/* ---- step level ---------------------------------------------------------------------
+ * voc_analysis_step  replaces analysisStep h eN prev_ph vec          Vocoder.hs:158-163
+ *                    (frameFromComplex :217-218, calcPhaseInc :169-173, wrap :166-167)
+ * voc_synthesis_step replaces synthesisStep hop ph (mag, ph_inc)      Vocoder.hs:186-190
+ *                    (frameToComplex :213-214)
+ * voc_add_frames     replaces addFrames                               Vocoder.hs:220-222
+ * B independent frames per call; prev_ph / ph are [B][K].  ph_out may alias prev_ph / ph.
+ */
+int32_t voc_analysis_step(voc_ctx *ctx, const double *prev_ph, const double *spec, double *ph_out, double *mag,
+                          double *ph_inc, int64_t batch);
+int32_t voc_synthesis_step(voc_ctx *ctx, const double *ph, const double *mag, const double *ph_inc, double *ph_out,
+                           double *spec, int64_t batch);
+int32_t voc_add_frames(voc_ctx *ctx, const double *mag1, const double *inc1, const double *mag2, const double *inc2,
+                       double *mag_out, double *inc_out, int64_t batch);
+
+/* ---- stage level (the batched hot path) -----------------------------------------------
+ * voc_analysis_stage  replaces analysisStage par ph frames           Vocoder.hs:149-150
+ *                     = mapAccumL (analysisBlock par)                Vocoder.hs:153-154
+ * voc_synthesis_stage replaces synthesisStage par ph stft            Vocoder.hs:177-178
+ *                     = mapAccumL (synthesisBlock par)               Vocoder.hs:181-182
+ * C channels are C independent mapAccumL folds sharing one VocoderParams, as
+ * analysisF / synthesisF do (vocoder-conduit/src/Vocoder/Conduit.hs:63-68).
+ *   phase_io [C][K]: in = phase before the first frame, out = phase after the last
+ *   frames   [C][F][W], mag / ph_inc [C][F][K].  C = 1 is the reference signature.
+ */
+int32_t voc_analysis_stage(voc_ctx *ctx, double *phase_io, const double *frames, double *mag, double *ph_inc,
+                           int64_t channels, int64_t nframes);
+int32_t voc_synthesis_stage(voc_ctx *ctx, double *phase_io, const double *mag, const double *ph_inc, double *frames,
+                            int64_t channels, int64_t nframes);
+int32_t voc_analysis_stage_dev(voc_ctx *ctx, double *phase_io, const double *frames, double *mag, double *ph_inc,
+                               int64_t channels, int64_t nframes, void *stream);
+int32_t voc_synthesis_stage_dev(voc_ctx *ctx, double *phase_io, const double *mag, const double *ph_inc,
+                                double *frames, int64_t channels, int64_t nframes, void *stream);
+
+/* ---- framing and overlap-add --------------------------------------------------------------
+ * voc_num_frames     frames genFramesOfE yields for `length` buffered samples: offsets
+ *                    0, H, .. <= length - W          vocoder-conduit/src/Vocoder/Conduit/Frames.hs:34-35
+ * voc_leftover_length samples genFramesOfE keeps as state: drop ((len-W) div H)*H + H   Frames.hs:36-37
+ * voc_ola_length     samples sumFramesE chunk H emits for F frames: the last chunk is
+ *                    zero-padded to `chunk`                          Frames.hs:45-47,57
+ * voc_frames_of      replaces genFramesOfE W H q on one whole buffer per channel   Frames.hs:26-38
+ *                    x [C][x_stride] (first `length` used) -> frames [C][F][W]
+ * voc_sum_frames     replaces sumFramesE chunk H                     Frames.hs:41-58
+ *                    frames [C][F][W] -> y [C][y_stride] (first voc_ola_length used)
+ */
+int64_t voc_num_frames(const voc_ctx *ctx, int64_t length);
+int64_t voc_leftover_length(const voc_ctx *ctx, int64_t length);
+int64_t voc_ola_length(const voc_ctx *ctx, int64_t nframes, int64_t chunk);
+int32_t voc_frames_of(voc_ctx *ctx, const double *x, int64_t x_stride, int64_t length, int64_t channels,
+                      double *frames);
+int32_t voc_sum_frames(voc_ctx *ctx, const double *frames, int64_t nframes, int64_t channels, int64_t chunk,
+                       double *y, int64_t y_stride);
+
+/* ---- fused round trip (the metric path) --------------------------------------------------------
+ * voc_roundtrip replaces, per channel, Vocoder.Conduit's
+ *     genFramesOfE W H q  `fuseBoth`  processFrames par phs idFilter  `fuseUpstream`  sumFramesE chunk H
+ * i.e. framing, analysis, volumeFix (mag * volumeCoeff), identity filter, synthesis and
+ * overlap-add (vocoder-conduit/src/Vocoder/Conduit.hs:34-35,46-53; with chunk = H this is
+ * `process`, with the caller's q / phases it is the `processWith` loop that
+ * vocoder-audio threads between sources, vocoder-audio/src/Vocoder/Audio.hs:31-33,86-91).
+ *   x            [C][x_stride]: previous leftover ++ new samples, `length` per channel
+ *   y            [C][y_stride]: receives voc_ola_length(voc_num_frames(length), chunk) samples
+ *   ana_phase_io, syn_phase_io [C][K]: in = phases before, out = phases after
+ *   leftover     [C][leftover_stride] or NULL: receives the voc_leftover_length(length) trailing samples
+ * The STFT (mag, ph_inc) of every frame is written once to and read once from device
+ * workspace between the two halves, where a frequency-domain filter would sit.
+ * voc_roundtrip_workspace_bytes: device bytes the _dev form needs to run all channels in one
+ * pass; with a smaller (or NULL) workspace the library processes the channels in groups
+ * (NULL: it keeps a grow-only workspace of its own in the context).
+ */
+int32_t voc_roundtrip(voc_ctx *ctx, const double *x, int64_t x_stride, int64_t length, int64_t channels,
+                      int64_t chunk, double *y, int64_t y_stride, double *ana_phase_io, double *syn_phase_io,
+                      double *leftover, int64_t leftover_stride);
+int64_t voc_roundtrip_workspace_bytes(const voc_ctx *ctx, int64_t length, int64_t channels);
+int32_t voc_roundtrip_dev(voc_ctx *ctx, const double *x, int64_t x_stride, int64_t length, int64_t channels,
+                          int64_t chunk, double *y, int64_t y_stride, double *ana_phase_io, double *syn_phase_io,
+                          double *leftover, int64_t leftover_stride, void *workspace, int64_t workspace_bytes,
+                          void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOCODER_HIP_H */

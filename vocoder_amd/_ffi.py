@@ -1,0 +1,99 @@
+"""ctypes binding of the C ABI declared in include/vocoder_hip.h.
+
+The product path loads ``vocoder_amd/libvocoder_hip.so`` (built by hipcc for gfx950) and
+raises if it is missing: there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libvocoder_hip.so")
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+_i32, _i64 = C.c_int32, C.c_int64
+
+# name -> (restype, argtypes); mirrors include/vocoder_hip.h one to one
+SIGNATURES = {
+    "voc_strerror": (C.c_char_p, [_i32]),
+    "voc_last_hip_error": (C.c_char_p, [_vp]),
+    "voc_ctx_create": (_i32, [_i32, _i32, _vp, _i32, _i32, _i32, C.POINTER(_vp)]),
+    "voc_ctx_destroy": (_i32, [_vp]),
+    "voc_frame_length": (_i32, [_vp]),
+    "voc_input_frame_length": (_i32, [_vp]),
+    "voc_freq_frame_length": (_i32, [_vp]),
+    "voc_hop_size": (_i32, [_vp]),
+    "voc_window": (_i32, [_vp, _vp]),
+    "voc_volume_coeff": (C.c_double, [_vp]),
+    "voc_r2c": (_i32, [_vp, _vp, _vp, _i64]),
+    "voc_c2r": (_i32, [_vp, _vp, _vp, _i64]),
+    "voc_do_fft": (_i32, [_vp, _vp, _vp, _i64]),
+    "voc_do_ifft": (_i32, [_vp, _vp, _vp, _i64]),
+    "voc_analysis_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64]),
+    "voc_synthesis_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64]),
+    "voc_add_frames": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64]),
+    "voc_analysis_stage": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64]),
+    "voc_synthesis_stage": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64]),
+    "voc_analysis_stage_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "voc_synthesis_stage_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "voc_num_frames": (_i64, [_vp, _i64]),
+    "voc_leftover_length": (_i64, [_vp, _i64]),
+    "voc_ola_length": (_i64, [_vp, _i64, _i64]),
+    "voc_frames_of": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp]),
+    "voc_sum_frames": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i64]),
+    "voc_roundtrip": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64]),
+    "voc_roundtrip_workspace_bytes": (_i64, [_vp, _i64, _i64]),
+    "voc_roundtrip_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
+}
+
+
+class VocoderError(RuntimeError):
+    """A C-ABI call returned a non-zero status (the reference raises `error` here)."""
+
+    def __init__(self, status: int, text: str):
+        super().__init__(f"vocoder_hip: {text} (status {status})")
+        self.status = status
+
+
+class Library:
+    """One loaded copy of the C-ABI library."""
+
+    def __init__(self, path: str | None = None):
+        path = path or DEFAULT_LIB
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} is missing: build it with `make -C vocoder_amd/csrc` (hipcc, gfx950). "
+                "vocoder_amd has no CPU fallback.")
+        if path == DEFAULT_LIB:
+            # share the HIP runtime PyTorch already loaded (same soname), when PyTorch is in use
+            import sys
+            if "torch" not in sys.modules:
+                try:
+                    import torch  # noqa: F401
+                except Exception:  # torch is plumbing only; the library also runs without it
+                    pass
+        self.path = path
+        self.dll = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self.dll, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+
+    def check(self, status: int, ctx=None):
+        if status != 0:
+            text = self.dll.voc_strerror(status).decode()
+            if ctx is not None and status == -3:
+                text += ": " + self.dll.voc_last_hip_error(ctx).decode()
+            raise VocoderError(status, text)
+
+
+_default: Library | None = None
+
+
+def default_library() -> Library:
+    global _default
+    if _default is None:
+        _default = Library()
+    return _default

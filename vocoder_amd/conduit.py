@@ -1,0 +1,116 @@
+"""Batch forms of the reference's streaming wrappers (vocoder-conduit/src/Vocoder/Conduit.hs and
+Conduit/Frames.hs) over the C ABI.
+
+The reference threads three pieces of state between chunks / sources: the samples genFramesOfE
+has not yet consumed, and the analysis and synthesis phases (Conduit.hs:46-53,
+vocoder-audio/src/Vocoder/Audio.hs:31-33).  `process_with` takes and returns exactly that
+triple, so a long stream can be fed segment by segment; `process` is the reference's
+`process` (empty leftover, zero phases, results of the state discarded).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .vocoder import VocoderParams, _f64, _p, zero_phase
+
+__all__ = ["num_frames", "leftover_length", "ola_length", "frames_of_e", "sum_frames_e", "process_with",
+           "process", "process_dev", "roundtrip_workspace_bytes"]
+
+
+def num_frames(par: VocoderParams, length: int) -> int:
+    return par.lib.dll.voc_num_frames(par.handle, int(length))
+
+
+def leftover_length(par: VocoderParams, length: int) -> int:
+    return par.lib.dll.voc_leftover_length(par.handle, int(length))
+
+
+def ola_length(par: VocoderParams, nframes: int, chunk: int) -> int:
+    return par.lib.dll.voc_ola_length(par.handle, int(nframes), int(chunk))
+
+
+def frames_of_e(par: VocoderParams, x):
+    """genFramesOfE W H on one whole buffer per channel (Frames.hs:26-38).
+    x: (L,) or (C, L) -> (frames (.., F, W), leftover (.., L - F*H))."""
+    x = _f64(x)
+    multi = x.ndim == 2
+    x2 = x if multi else x[None]
+    c, length = x2.shape
+    f = num_frames(par, length)
+    frames = np.empty((c, f, par.W))
+    par._call("voc_frames_of", _p(x2), length, length, c, _p(frames))
+    keep = leftover_length(par, length)
+    left = x2[:, length - keep:].copy()
+    return (frames, left) if multi else (frames[0], left[0])
+
+
+def sum_frames_e(par: VocoderParams, frames, chunk: int | None = None):
+    """sumFramesE chunk H (Frames.hs:41-58). frames: (F, W) or (C, F, W) -> (.., out_len)."""
+    frames = _f64(frames)
+    multi = frames.ndim == 3
+    fr = frames if multi else frames[None]
+    c, f, _ = fr.shape
+    chunk = par.H if chunk is None else chunk
+    n = ola_length(par, f, chunk)
+    y = np.zeros((c, n))
+    par._call("voc_sum_frames", _p(fr), f, c, chunk, _p(y), n)
+    return y if multi else y[0]
+
+
+def process_with(par: VocoderParams, x, leftover=None, phases=None, chunk: int | None = None):
+    """One `processWith q phs idFilter` step (Conduit.hs:53): returns (y, leftover', (ana_ph', syn_ph')).
+    x: (L,) or (C, L) new samples; leftover: (.., r) samples kept from the previous call."""
+    x = _f64(x)
+    multi = x.ndim == 2
+    x2 = x if multi else x[None]
+    c = x2.shape[0]
+    if leftover is not None and np.size(leftover):
+        x2 = np.concatenate([_f64(leftover).reshape(c, -1), x2], axis=1)
+    x2 = np.ascontiguousarray(x2)
+    length = x2.shape[1]
+    chunk = par.H if chunk is None else chunk
+    f = num_frames(par, length)
+    n = ola_length(par, f, chunk)
+    keep = leftover_length(par, length)
+    if phases is None:
+        aph, sph = zero_phase(par, c), zero_phase(par, c)
+    else:
+        aph = np.array(phases[0], dtype=np.float64, copy=True).reshape(c, par.K)
+        sph = np.array(phases[1], dtype=np.float64, copy=True).reshape(c, par.K)
+    y = np.empty((c, n))
+    left = np.empty((c, keep))
+    par._call("voc_roundtrip", _p(x2), length, length, c, chunk, _p(y), n, _p(aph), _p(sph), _p(left), keep)
+    if not multi:
+        return y[0], left[0], (aph[0], sph[0])
+    return y, left, (aph, sph)
+
+
+def process(par: VocoderParams, x):
+    """Vocoder.Conduit.process par idFilter on a whole buffer (Conduit.hs:50-53)."""
+    return process_with(par, x)[0]
+
+
+def roundtrip_workspace_bytes(par: VocoderParams, length: int, channels: int) -> int:
+    return par.lib.dll.voc_roundtrip_workspace_bytes(par.handle, int(length), int(channels))
+
+
+def process_dev(par: VocoderParams, x, y, ana_phase, syn_phase, length: int | None = None, chunk: int | None = None,
+                leftover=None, workspace=None, stream=None):
+    """Device-resident `process_with`: x (C, >=length), y (C, >=ola_length), phases (C, K) and the
+    optional leftover / workspace are torch CUDA float64 / uint8 tensors; enqueues on `stream`
+    (default: torch's current stream) and returns without synchronising."""
+    import torch
+
+    assert x.is_cuda and y.is_cuda and x.dtype == torch.float64 and y.dtype == torch.float64
+    assert x.stride(-1) == 1 and y.stride(-1) == 1 and ana_phase.is_contiguous() and syn_phase.is_contiguous()
+    c = x.shape[0]
+    length = x.shape[1] if length is None else length
+    chunk = par.H if chunk is None else chunk
+    st = torch.cuda.current_stream(x.device).cuda_stream if stream is None else stream
+    lp, ls = (None, 0) if leftover is None else (C.c_void_p(leftover.data_ptr()), leftover.stride(0))
+    wp, wb = (None, 0) if workspace is None else (C.c_void_p(workspace.data_ptr()), workspace.numel() * workspace.element_size())
+    par._call("voc_roundtrip_dev", C.c_void_p(x.data_ptr()), x.stride(0), length, c, chunk,
+              C.c_void_p(y.data_ptr()), y.stride(0), C.c_void_p(ana_phase.data_ptr()),
+              C.c_void_p(syn_phase.data_ptr()), lp, ls, wp, wb, C.c_void_p(st))

@@ -1,0 +1,641 @@
+// voc_kernels.h -- gfx950 kernels of the phase-vocoder round trip.
+//
+// One workgroup owns one (channel, run of consecutive frames) tile and walks its
+// frames in order.  A frame of N reals is transformed as an M = N/2 point complex
+// FFT (even samples -> re, odd samples -> im) held in LDS, Stockham radix-8/4/2
+// passes with the butterflies in registers, followed by the real-FFT split.
+// Everything around the FFT (window, zero pad, rewind, polar conversion, phase
+// increment, phase accumulation, polar->complex, cut, window, overlap-add) is
+// fused into the same kernel so that a frame touches HBM once on the way in
+// and once on the way out.
+//
+// Arithmetic notes: the file is compiled with -ffp-contract=off; every fused
+// multiply-add below is an explicit fma().  Operations whose rounding sequence
+// the reference fixes (phase increment, wrap, phase accumulation, magnitude
+// scaling, overlap-add order) are written as separate multiplies and adds in
+// the reference's order.
+#pragma once
+
+namespace voc {
+
+#define VOC_DEV __device__ __forceinline__
+
+#ifdef VOC_EMU
+#define VOC_SMEM(type, name) type *name = reinterpret_cast<type *>(emu::tls.smem)
+#else
+#define VOC_SMEM(type, name)                                                        \
+    extern __shared__ __attribute__((aligned(16))) unsigned char voc_smem_raw[];    \
+    type *name = reinterpret_cast<type *>(voc_smem_raw)
+#endif
+
+constexpr double kPi = 3.141592653589793238462643383279502884;  // GHC `pi :: Double`
+constexpr double kTwoPi = 2.0 * kPi;
+constexpr double kInvTwoPi = 0.15915494309189533576888376337251436;
+constexpr double kSqrtHalf = 0.70710678118654752440084436210484904;
+
+struct Params {
+    int N, W, H, K, M;
+    int hd;        // zeros addZeroPadding puts in front: diff - diff div 2        (Vocoder.hs:138)
+    int off;       // cutCenter offset (N - W) div 2                               (Vocoder.hs:200)
+    int hop_pow2;  // H is a power of two: x / H == x * (1/H) exactly
+    double hop_d, inv_hop, inv_n;
+    const double *window;  // [W]
+    const double2 *twM;    // [M]      exp(-2 pi i m / M)
+    const double2 *twS;    // [M/2+1]  exp(-2 pi i k / N)
+};
+
+template <int LOG2M>
+struct Cfg {
+    static constexpr int M = 1 << LOG2M;
+    static constexpr int T = (M / 8) < 64 ? 64 : ((M / 8) > 1024 ? 1024 : (M / 8));  // threads per frame
+    static constexpr int NP = ((M / 2) / T) < 1 ? 1 : ((M / 2) / T);                 // (k, M-k) bin pairs per thread
+    static constexpr int NQ = (M / T) < 1 ? 1 : (M / T);                             // complex points per thread
+    static constexpr int LDS_CPLX = M + (M >> 3) + 2;
+};
+
+// ------------------------------------------------------------------ complex helpers
+VOC_DEV double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+VOC_DEV double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+VOC_DEV double2 cmul(double2 a, double2 b)
+{
+    return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x));
+}
+VOC_DEV double2 cmul_conj(double2 a, double2 b)  // a * conj(b)
+{
+    return make_double2(fma(a.x, b.x, a.y * b.y), fma(a.y, b.x, -(a.x * b.y)));
+}
+VOC_DEV double2 mul_mi(double2 a) { return make_double2(a.y, -a.x); }  // a * (-i)
+VOC_DEV double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
+VOC_DEV int lds_pad(int i) { return i + (i >> 3); }
+
+VOC_DEV void bf2(double2 &a, double2 &b)
+{
+    double2 t = a;
+    a = cadd(t, b);
+    b = csub(t, b);
+}
+
+// Forward DFT of RAD points in place, natural order in and out.
+template <int RAD>
+VOC_DEV void dft(double2 (&v)[RAD]);
+
+template <>
+VOC_DEV void dft<2>(double2 (&v)[2]) { bf2(v[0], v[1]); }
+
+template <>
+VOC_DEV void dft<4>(double2 (&v)[4])
+{
+    bf2(v[0], v[2]);
+    bf2(v[1], v[3]);
+    v[3] = mul_mi(v[3]);
+    bf2(v[0], v[1]);
+    bf2(v[2], v[3]);
+    double2 t = v[1];  // bit-reversed -> natural
+    v[1] = v[2];
+    v[2] = t;
+}
+
+template <>
+VOC_DEV void dft<8>(double2 (&v)[8])
+{
+    bf2(v[0], v[4]);
+    bf2(v[1], v[5]);
+    bf2(v[2], v[6]);
+    bf2(v[3], v[7]);
+    // twiddles W8^1, W8^2, W8^3 on the lower half
+    v[5] = make_double2((v[5].x + v[5].y) * kSqrtHalf, (v[5].y - v[5].x) * kSqrtHalf);
+    v[6] = mul_mi(v[6]);
+    v[7] = make_double2((v[7].y - v[7].x) * kSqrtHalf, -((v[7].x + v[7].y) * kSqrtHalf));
+    bf2(v[0], v[2]);
+    bf2(v[1], v[3]);
+    v[3] = mul_mi(v[3]);
+    bf2(v[4], v[6]);
+    bf2(v[5], v[7]);
+    v[7] = mul_mi(v[7]);
+    bf2(v[0], v[1]);
+    bf2(v[2], v[3]);
+    bf2(v[4], v[5]);
+    bf2(v[6], v[7]);
+    // registers now hold y0 y4 y2 y6 y1 y5 y3 y7
+    double2 t;
+    t = v[1]; v[1] = v[4]; v[4] = t;
+    t = v[3]; v[3] = v[6]; v[6] = t;
+}
+
+// One Stockham pass of radix RAD at stride NS over M points.  Butterfly i reads
+// in[i + j*M/RAD], multiplies by exp(-2 pi i j k / (NS*RAD)) with k = i mod NS, and
+// writes out[(i-k)*RAD + k + j*NS].  Reads come through `ld` (LDS or a fused global
+// loader for the first pass); writes go to LDS in place, fenced by two barriers.
+template <int M, int T, int NS, class Loader>
+VOC_DEV void fft_passes(double2 *lds, const double2 *__restrict__ twM, int tid, Loader ld)
+{
+    constexpr int REM = M / NS;
+    constexpr int RAD = REM >= 8 ? 8 : REM;
+    constexpr int NBF = M / RAD;
+    constexpr int NB = (NBF + T - 1) / T;
+    constexpr int TWS = M / (NS * RAD);
+    double2 v[NB][RAD];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const int i = tid + q * T;
+        if ((NBF % T == 0) || i < NBF) {
+#pragma unroll
+            for (int j = 0; j < RAD; ++j) v[q][j] = ld(i + j * NBF);
+            if (NS > 1) {
+                const int k = i & (NS - 1);
+#pragma unroll
+                for (int j = 1; j < RAD; ++j) v[q][j] = cmul(v[q][j], twM[j * k * TWS]);
+            }
+            dft<RAD>(v[q]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const int i = tid + q * T;
+        if ((NBF % T == 0) || i < NBF) {
+            const int k = i & (NS - 1);
+            const int j0 = (i - k) * RAD + k;
+#pragma unroll
+            for (int j = 0; j < RAD; ++j) lds[lds_pad(j0 + j * NS)] = v[q][j];
+        }
+    }
+    __syncthreads();
+    if constexpr (NS * RAD < M) {
+        fft_passes<M, T, NS * RAD>(lds, twM, tid, [lds](int m) { return lds[lds_pad(m)]; });
+    }
+}
+
+// ------------------------------------------------------------------ per-bin arithmetic
+
+// Data.Complex.magnitude: scaleFloat k (sqrt (sqr (scaleFloat (-k) x) + sqr (scaleFloat (-k) y))),
+// k = max (exponent x) (exponent y), exponent 0 = 0.
+VOC_DEV double hs_magnitude(double x, double y)
+{
+    int ex = 0, ey = 0;
+    if (x != 0.0) (void)frexp(x, &ex);
+    if (y != 0.0) (void)frexp(y, &ey);
+    const int k = ex > ey ? ex : ey;
+    const double sx = ldexp(x, -k), sy = ldexp(y, -k);
+    const double a = sx * sx, b = sy * sy;
+    return ldexp(sqrt(a + b), k);
+}
+
+// Data.Complex.phase: 0 for 0:+0, else atan2 y x (range (-pi, pi], atan2(+0, x<0) = pi).
+VOC_DEV double hs_phase(double x, double y) { return (x == 0.0 && y == 0.0) ? 0.0 : atan2(y, x); }
+
+// wrap e = (e + pi) `mod'` (2 pi) - pi with mod' n d = n - floor(n/d) * d and the floor taken
+// of the exact quotient (Vocoder.hs:166-167, Data.Fixed).  The exact floor is recovered from
+// an approximate quotient through the sign of the exactly rounded remainder.
+VOC_DEV double hs_wrap(double e)
+{
+    const double n = e + kPi;
+    double f = floor(n * kInvTwoPi);
+    if (fma(-f, kTwoPi, n) < 0.0) f -= 1.0;
+    else if (fma(-(f + 1.0), kTwoPi, n) >= 0.0) f += 1.0;
+    const double t = f * kTwoPi;
+    return (n - t) - kPi;
+}
+
+// calcPhaseInc (Vocoder.hs:169-173): omega = ((2 pi k) H) / N ; (omega + wrap (d - omega)) / H
+VOC_DEV double phase_inc(const Params &p, int k, double ph_diff)
+{
+    const double omega = ((kTwoPi * (double)k) * p.hop_d) * p.inv_n;
+    const double s = omega + hs_wrap(ph_diff - omega);
+    return p.hop_pow2 ? s * p.inv_hop : s / p.hop_d;
+}
+
+// analysisStep for one bin (Vocoder.hs:158-163).  `prev` is replaced by the new raw phase.
+VOC_DEV void analyze_bin(const Params &p, int k, double2 X, double &prev, bool emit, double vol, double *mag, double *inc)
+{
+    const double ph = hs_phase(X.x, X.y);
+    if (emit) {
+        *mag = hs_magnitude(X.x, X.y) * vol;
+        *inc = phase_inc(p, k, ph - prev);
+    }
+    prev = ph;
+}
+
+// synthesisStep for one bin (Vocoder.hs:186-190): ph + (ph_inc * H), then mkPolar.
+VOC_DEV double2 synthesize_bin(const Params &p, double mag, double inc, double &ph)
+{
+    const double t = inc * p.hop_d;
+    ph = ph + t;
+    double s, c;
+    sincos(ph, &s, &c);
+    return make_double2(mag * c, mag * s);
+}
+
+// ------------------------------------------------------------------ analysis
+
+struct AnaArgs {
+    const double *x;        // frame (c, f) starts at x + c*chan_stride + f*frame_stride
+    long long chan_stride;  // [C][F][W]: F*W ; raw signal: samples per channel row
+    long long frame_stride; // [C][F][W]: W   ; raw signal: H
+    const double *phase_in; // [C][K]
+    double *phase_out;      // [C][K]
+    double *mag, *inc;      // [(c*F + f)*ldk + k]
+    double *spec;           // SPEC_OUT: [(c*F + f)*K + k] complex
+    long long ldk;
+    long long F;
+    int tile_len, tiles;
+    double vol;             // factor folded into mag (volumeFix), 1 for the plain stage
+};
+
+// RAW: plain R2C of N contiguous reals (no window / pad / rewind).  SPEC_OUT: write the complex
+// spectrum instead of (mag, ph_inc).
+template <int LOG2M, bool RAW, bool SPEC_OUT>
+__global__ void __launch_bounds__(Cfg<LOG2M>::T) analysis_kernel(Params p, AnaArgs a)
+{
+    constexpr int M = Cfg<LOG2M>::M, T = Cfg<LOG2M>::T, NP = Cfg<LOG2M>::NP;
+    VOC_SMEM(double2, lds);
+    const int tid = threadIdx.x;
+    const long long c = blockIdx.x / a.tiles;
+    const int tile = blockIdx.x % a.tiles;
+    const long long f0 = (long long)tile * a.tile_len;
+    const long long f1 = (f0 + a.tile_len < a.F) ? f0 + a.tile_len : a.F;
+    const double *xc = a.x + c * a.chan_stride;
+    const bool own_half = (tid == T - 1);  // the thread that also owns bin M/2
+
+    double prev[2 * NP + 1];
+    if (!SPEC_OUT && f0 == 0) {
+        const double *pi = a.phase_in + c * p.K;
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+            const int pr = tid + m * T;
+            if (pr < M / 2) {
+                prev[2 * m] = pi[pr];
+                prev[2 * m + 1] = pi[M - pr];
+            }
+        }
+        if (own_half) prev[2 * NP] = pi[M / 2];
+    }
+
+    const long long fs = (!SPEC_OUT && f0 > 0) ? f0 - 1 : f0;  // one frame early to recover its raw phase
+    for (long long f = fs; f < f1; ++f) {
+        const double *fr = xc + f * a.frame_stride;
+        const bool emit = f >= f0;
+        // ---- first pass reads straight from global: window, zero pad, rewind, even/odd packing
+        auto loader = [&](int m) -> double2 {
+            if (RAW) return make_double2(fr[2 * m], fr[2 * m + 1]);
+            const int i0 = ((2 * m + M) & (p.N - 1)) - p.hd;       // rewind: v[n] = padded[(n + N/2) mod N]
+            const int i1 = ((2 * m + 1 + M) & (p.N - 1)) - p.hd;
+            double2 z;
+            z.x = (i0 >= 0 && i0 < p.W) ? p.window[i0] * fr[i0] : 0.0;
+            z.y = (i1 >= 0 && i1 < p.W) ? p.window[i1] * fr[i1] : 0.0;
+            return z;
+        };
+        fft_passes<M, T, 1>(lds, p.twM, tid, loader);
+        // ---- real-FFT split + per-bin analysis.  Z[k] is at lds[pad(k)].
+        const long long row = c * a.F + f;
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+            const int pr = tid + m * T;
+            if (pr < M / 2) {
+                double2 Xa, Xb;  // bins pr and M - pr
+                if (pr == 0) {
+                    const double2 z0 = lds[lds_pad(0)];
+                    Xa = make_double2(z0.x + z0.y, 0.0);
+                    Xb = make_double2(z0.x - z0.y, 0.0);
+                } else {
+                    const double2 P = lds[lds_pad(pr)], Q = lds[lds_pad(M - pr)];
+                    const double2 E = make_double2(0.5 * (P.x + Q.x), 0.5 * (P.y - Q.y));
+                    const double2 O = make_double2(0.5 * (P.y + Q.y), 0.5 * (Q.x - P.x));  // (P - conj Q) / (2i)
+                    const double2 U = cmul(p.twS[pr], O);
+                    Xa = cadd(E, U);
+                    Xb = cconj(csub(E, U));
+                }
+                if (SPEC_OUT) {
+                    double *s = a.spec + row * 2 * p.K;
+                    s[2 * pr] = Xa.x;
+                    s[2 * pr + 1] = Xa.y;
+                    s[2 * (M - pr)] = Xb.x;
+                    s[2 * (M - pr) + 1] = Xb.y;
+                } else {
+                    double mg, ic;
+                    analyze_bin(p, pr, Xa, prev[2 * m], emit, a.vol, &mg, &ic);
+                    if (emit) {
+                        a.mag[row * a.ldk + pr] = mg;
+                        a.inc[row * a.ldk + pr] = ic;
+                    }
+                    analyze_bin(p, M - pr, Xb, prev[2 * m + 1], emit, a.vol, &mg, &ic);
+                    if (emit) {
+                        a.mag[row * a.ldk + (M - pr)] = mg;
+                        a.inc[row * a.ldk + (M - pr)] = ic;
+                    }
+                }
+            }
+        }
+        if (own_half) {
+            const double2 X = cconj(lds[lds_pad(M / 2)]);  // W^(M/2) = -i
+            if (SPEC_OUT) {
+                double *s = a.spec + row * 2 * p.K;
+                s[M] = X.x;
+                s[M + 1] = X.y;
+            } else {
+                double mg, ic;
+                analyze_bin(p, M / 2, X, prev[2 * NP], emit, a.vol, &mg, &ic);
+                if (emit) {
+                    a.mag[row * a.ldk + M / 2] = mg;
+                    a.inc[row * a.ldk + M / 2] = ic;
+                }
+            }
+        }
+        // the next frame's first LDS write sits behind the barrier inside fft_passes
+    }
+
+    if (!SPEC_OUT && f1 == a.F && f1 > f0) {
+        double *po = a.phase_out + c * p.K;
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+            const int pr = tid + m * T;
+            if (pr < M / 2) {
+                po[pr] = prev[2 * m];
+                po[M - pr] = prev[2 * m + 1];
+            }
+        }
+        if (own_half) po[M / 2] = prev[2 * NP];
+    }
+}
+
+// ------------------------------------------------------------------ synthesis
+
+enum { SYN_IN_POLAR = 0, SYN_IN_SPEC = 1 };
+enum { SYN_OUT_FRAMES = 0, SYN_OUT_RAW = 1, SYN_OUT_OLA = 2 };
+
+struct SynArgs {
+    const double *mag, *inc;  // [(c*F + f)*ldk + k]
+    long long ldk;
+    const double *spec;       // IN_SPEC: [(c*F + f)*K + k] complex
+    const double *phase_in;   // [C][K]           chain start of tile 0
+    const double *carry;      // [C][tiles][K]    chain start of tiles > 0
+    double *phase_out;        // [C][K]
+    double *out;              // FRAMES: [(c*F + f)*W + i]; RAW: [(c*F + f)*N + n]; OLA: [c*out_stride + s]
+    long long out_stride;
+    long long out_len;        // OLA: samples per channel, last chunk zero padded
+    long long F;
+    int tile_len, tiles, halo;
+};
+
+template <int LOG2M, int IN_MODE, int OUT_MODE>
+__global__ void __launch_bounds__(Cfg<LOG2M>::T) synthesis_kernel(Params p, SynArgs a)
+{
+    constexpr int M = Cfg<LOG2M>::M, T = Cfg<LOG2M>::T, NP = Cfg<LOG2M>::NP, NQ = Cfg<LOG2M>::NQ;
+    VOC_SMEM(double2, lds);
+    double *ring = reinterpret_cast<double *>(lds + Cfg<LOG2M>::LDS_CPLX);  // OLA partial sums, W doubles
+    const int tid = threadIdx.x;
+    const long long c = blockIdx.x / a.tiles;
+    const int tile = blockIdx.x % a.tiles;
+    const long long f0 = (long long)tile * a.tile_len;
+    const long long f1 = (f0 + a.tile_len < a.F) ? f0 + a.tile_len : a.F;
+    const bool own_half = (tid == T - 1);
+    // OLA: frames that reach into this tile's first output sample are recomputed, in order,
+    // so that every output sample is summed oldest frame first with no cross-tile exchange.
+    const long long halo = (OUT_MODE == SYN_OUT_OLA) ? ((long long)a.halo < f0 ? (long long)a.halo : f0) : 0;
+    const long long fs = f0 - halo;
+
+    double ph[2 * NP + 1];
+    if (IN_MODE == SYN_IN_POLAR) {
+        const double *pi = (tile == 0) ? a.phase_in + c * p.K : a.carry + (c * a.tiles + tile) * p.K;
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+            const int pr = tid + m * T;
+            if (pr < M / 2) {
+                ph[2 * m] = pi[pr];
+                ph[2 * m + 1] = pi[M - pr];
+            }
+        }
+        if (own_half) ph[2 * NP] = pi[M / 2];
+    }
+    int base = 0;
+    if (OUT_MODE == SYN_OUT_OLA) {
+        for (int i = tid; i < p.W; i += T) ring[i] = 0.0;
+    }
+
+    for (long long f = fs; f < f1; ++f) {
+        const long long row = c * a.F + f;
+        // ---- spectrum of this frame -> half-length complex input Z (stored re<->im swapped so
+        //      that the forward FFT below performs the backward transform)
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+            const int pr = tid + m * T;
+            if (pr < M / 2) {
+                double2 A, B;  // X[pr], X[M - pr]
+                if (IN_MODE == SYN_IN_POLAR) {
+                    A = synthesize_bin(p, a.mag[row * a.ldk + pr], a.inc[row * a.ldk + pr], ph[2 * m]);
+                    B = synthesize_bin(p, a.mag[row * a.ldk + (M - pr)], a.inc[row * a.ldk + (M - pr)], ph[2 * m + 1]);
+                } else {
+                    const double *s = a.spec + row * 2 * p.K;
+                    A = make_double2(s[2 * pr], s[2 * pr + 1]);
+                    B = make_double2(s[2 * (M - pr)], s[2 * (M - pr) + 1]);
+                }
+                if (pr == 0) {  // DC and Nyquist: imaginary parts ignored
+                    lds[lds_pad(0)] = make_double2(A.x - B.x, A.x + B.x);  // swapped (im, re)
+                } else {
+                    const double2 S = make_double2(A.x + B.x, A.y - B.y);   // A + conj B
+                    const double2 D = make_double2(A.x - B.x, A.y + B.y);   // A - conj B
+                    const double2 Tw = cmul_conj(D, p.twS[pr]);             // W^(-k) D
+                    // Z[k] = S + i Tw ; Z[M-k] = conj S + i conj Tw
+                    lds[lds_pad(pr)] = make_double2(S.y + Tw.x, S.x - Tw.y);
+                    lds[lds_pad(M - pr)] = make_double2(Tw.x - S.y, S.x + Tw.y);
+                }
+            }
+        }
+        if (own_half) {
+            double2 A;
+            if (IN_MODE == SYN_IN_POLAR) {
+                A = synthesize_bin(p, a.mag[row * a.ldk + M / 2], a.inc[row * a.ldk + M / 2], ph[2 * NP]);
+            } else {
+                const double *s = a.spec + row * 2 * p.K;
+                A = make_double2(s[M], s[M + 1]);
+            }
+            lds[lds_pad(M / 2)] = make_double2(-2.0 * A.y, 2.0 * A.x);  // Z = 2 conj A, swapped
+        }
+        __syncthreads();
+        fft_passes<M, T, 1>(lds, p.twM, tid, [lds](int m) { return lds[lds_pad(m)]; });
+        // ---- lds[pad(m)] = swapped z[m]: v[2m] = z.y / N, v[2m+1] = z.x / N  (C2R scaled by 1/N)
+        const bool emit = f >= f0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int m = tid + q * T;
+            if (m < M) {
+                const double2 z = lds[lds_pad(m)];
+                const double v0 = z.y * p.inv_n, v1 = z.x * p.inv_n;
+                if (OUT_MODE == SYN_OUT_RAW) {
+                    a.out[row * p.N + 2 * m] = v0;
+                    a.out[row * p.N + 2 * m + 1] = v1;
+                } else {
+                    // rewind again, cutCenter, window: frame[i] = w[i] * v[(i + off + N/2) mod N]
+                    const int i0 = (2 * m - M - p.off) & (p.N - 1);
+                    const int i1 = (2 * m + 1 - M - p.off) & (p.N - 1);
+                    if (OUT_MODE == SYN_OUT_FRAMES) {
+                        if (i0 < p.W) a.out[row * p.W + i0] = p.window[i0] * v0;
+                        if (i1 < p.W) a.out[row * p.W + i1] = p.window[i1] * v1;
+                    } else {
+                        if (i0 < p.W) {
+                            int r = base + i0;
+                            if (r >= p.W) r -= p.W;
+                            ring[r] = ring[r] + p.window[i0] * v0;
+                        }
+                        if (i1 < p.W) {
+                            int r = base + i1;
+                            if (r >= p.W) r -= p.W;
+                            ring[r] = ring[r] + p.window[i1] * v1;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (OUT_MODE == SYN_OUT_OLA) {
+            // the first H samples of the ring are complete: emit (if owned) and retire them
+            double *yc = a.out + c * a.out_stride;
+            for (int i = tid; i < p.H; i += T) {
+                double s = 0.0;
+                if (i < p.W) {
+                    int r = base + i;
+                    if (r >= p.W) r -= p.W;
+                    s = ring[r];
+                    ring[r] = 0.0;
+                }
+                const long long pos = f * p.H + i;
+                if (emit && pos < a.out_len) yc[pos] = s;
+            }
+            base += p.H % p.W;
+            if (base >= p.W) base -= p.W;
+            // ring updates of the next frame happen behind the barriers of its FFT
+        }
+    }
+
+    if (f1 == a.F && f1 > f0) {
+        if (IN_MODE == SYN_IN_POLAR) {
+            double *po = a.phase_out + c * p.K;
+#pragma unroll
+            for (int m = 0; m < NP; ++m) {
+                const int pr = tid + m * T;
+                if (pr < M / 2) {
+                    po[pr] = ph[2 * m];
+                    po[M - pr] = ph[2 * m + 1];
+                }
+            }
+            if (own_half) po[M / 2] = ph[2 * NP];
+        }
+        if (OUT_MODE == SYN_OUT_OLA) {
+            // tail after the last frame: the ring's remaining W - H partial sums, then zeros up to
+            // the end of the last chunk (sumFramesE pads it: Frames.hs:45-47)
+            __syncthreads();
+            double *yc = a.out + c * a.out_stride;
+            const long long start = a.F * p.H;
+            for (long long i = tid; start + i < a.out_len; i += T) {
+                double s = 0.0;
+                if (i < p.W - p.H) {
+                    int r = base + (int)i;
+                    if (r >= p.W) r -= p.W;
+                    s = ring[r];
+                }
+                yc[start + i] = s;
+            }
+        }
+    }
+}
+
+// Sequential phase chain per (channel, bin): ph <- ph + ph_inc * H frame after frame
+// (synthesisStep, Vocoder.hs:190), recording the chain value each synthesis tile starts from.
+// Tile t >= 1 starts computing at frame t*tile_len - halo.
+__global__ void phase_carry_kernel(Params p, const double *__restrict__ inc, long long ldk, long long F,
+                                   const double *__restrict__ phase_in, double *__restrict__ carry, int tile_len,
+                                   int tiles, int halo, long long channels)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= channels * p.K) return;
+    const long long c = g / p.K;
+    const int k = (int)(g % p.K);
+    double ph = phase_in[c * p.K + k];
+    const double *src = inc + c * F * ldk + k;
+    long long next = (long long)tile_len - halo;  // frame count after which tile 1 starts
+    int t = 1;
+    for (long long f = 0; f < F && t < tiles; ++f) {
+        const double d = src[f * ldk] * p.hop_d;
+        ph = ph + d;
+        if (f + 1 == next) {
+            carry[(c * tiles + t) * p.K + k] = ph;
+            ++t;
+            next += tile_len;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ step-level, framing, overlap-add
+
+// analysisStep over B independent frames (Vocoder.hs:158-163)
+__global__ void analysis_step_kernel(Params p, const double *prev_ph, const double *spec, double *ph_out, double *mag,
+                                     double *inc, long long total)
+{
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(g % p.K);
+        double prev = prev_ph[g], mg, ic;
+        analyze_bin(p, k, make_double2(spec[2 * g], spec[2 * g + 1]), prev, true, 1.0, &mg, &ic);
+        mag[g] = mg;
+        inc[g] = ic;
+        ph_out[g] = prev;
+    }
+}
+
+// synthesisStep over B independent frames (Vocoder.hs:186-190)
+__global__ void synthesis_step_kernel(Params p, const double *ph, const double *mag, const double *inc, double *ph_out,
+                                      double *spec, long long total)
+{
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        double cur = ph[g];
+        const double2 X = synthesize_bin(p, mag[g], inc[g], cur);
+        spec[2 * g] = X.x;
+        spec[2 * g + 1] = X.y;
+        ph_out[g] = cur;
+    }
+}
+
+// addFrames (Vocoder.hs:220-222): polar -> complex, add, complex -> polar
+__global__ void add_frames_kernel(const double *mag1, const double *inc1, const double *mag2, const double *inc2,
+                                  double *mag_out, double *inc_out, long long total)
+{
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        double s1, c1, s2, c2;
+        sincos(inc1[g], &s1, &c1);
+        sincos(inc2[g], &s2, &c2);
+        const double re = mag1[g] * c1 + mag2[g] * c2;
+        const double im = mag1[g] * s1 + mag2[g] * s2;
+        mag_out[g] = hs_magnitude(re, im);
+        inc_out[g] = hs_phase(re, im);
+    }
+}
+
+// genFramesOfE on a whole buffer: frame j = x[j*H .. j*H + W)  (Frames.hs:34-35)
+__global__ void frames_of_kernel(const double *x, long long x_stride, double *frames, long long F, int W, int H,
+                                 long long total)
+{
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(g % W);
+        const long long cf = g / W;
+        const long long f = cf % F, c = cf / F;
+        frames[g] = x[c * x_stride + f * H + i];
+    }
+}
+
+// sumFramesE: y[s] = sum over frames j covering s of frame_j[s - j*H], oldest frame first, folded
+// from 0 (Frames.hs:44-45); samples past the last frame's end are the zero padding of the last chunk.
+__global__ void sum_frames_kernel(const double *frames, long long F, int W, int H, double *y, long long y_stride,
+                                  long long out_len, long long total)
+{
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const long long s = g % out_len, c = g / out_len;
+        long long jlo = (s - W + H) / H;  // ceil((s - W + 1) / H) for s - W + 1 > 0
+        if (s - W + 1 <= 0) jlo = 0;
+        long long jhi = s / H;
+        if (jhi > F - 1) jhi = F - 1;
+        double acc = 0.0;
+        for (long long j = jlo; j <= jhi; ++j) acc = acc + frames[(c * F + j) * W + (s - j * H)];
+        y[c * y_stride + s] = acc;
+    }
+}
+
+}  // namespace voc

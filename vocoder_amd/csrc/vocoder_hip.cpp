@@ -1,0 +1,796 @@
+// vocoder_hip.cpp -- C-ABI implementation (include/vocoder_hip.h) over the gfx950 kernels.
+// Built by hipcc (-x hip --offload-arch=gfx950 -ffp-contract=off) into libvocoder_hip.so.
+#ifndef VOC_EMU
+#include <hip/hip_runtime.h>
+#endif
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/vocoder_hip.h"
+#include "voc_kernels.h"
+
+#define VOC_EXPORT extern "C" __attribute__((visibility("default")))
+
+struct voc_ctx {
+    int N = 0, W = 0, H = 0, K = 0, M = 0, log2m = 0, device = 0;
+    std::vector<double> window;
+    double vol = 0.0;
+    double *d_window = nullptr;
+    double2 *d_twM = nullptr, *d_twS = nullptr;
+    voc::Params params{};
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    int ana_tile_override = 0, syn_tile_override = 0;
+    std::mutex mu;
+    std::string hip_err;
+};
+
+namespace {
+
+struct HipFail {
+    hipError_t e;
+    const char *what;
+};
+
+#define HIPCHK(call)                          \
+    do {                                      \
+        hipError_t e_ = (call);               \
+        if (e_ != hipSuccess) throw HipFail{e_, #call}; \
+    } while (0)
+
+// Runs body() and maps failures to status codes; nothing propagates across the C boundary.
+template <class Body>
+int32_t guarded(voc_ctx *ctx, Body body)
+{
+    try {
+        return body();
+    } catch (const HipFail &f) {
+        if (ctx) ctx->hip_err = std::string(f.what) + ": " + hipGetErrorString(f.e);
+        return f.e == hipErrorOutOfMemory ? VOC_ERR_NOMEM : VOC_ERR_HIP;
+    } catch (const std::bad_alloc &) {
+        return VOC_ERR_NOMEM;
+    } catch (...) {
+        return VOC_ERR_INVALID;
+    }
+}
+
+struct DevBuf {  // device allocation owned for the duration of one host-pointer call
+    void *p = nullptr;
+    explicit DevBuf(size_t bytes) { HIPCHK(hipMalloc(&p, bytes ? bytes : 8)); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    double *d() const { return static_cast<double *>(p); }
+};
+
+inline long long floordiv(long long a, long long b)
+{
+    long long q = a / b;
+    if ((a % b != 0) && ((a < 0) != (b < 0))) --q;
+    return q;
+}
+
+inline int env_int(const char *name)
+{
+    const char *s = std::getenv(name);
+    return s ? std::atoi(s) : 0;
+}
+
+inline size_t lds_bytes(const voc_ctx *c, bool ola)
+{
+    size_t b = (size_t)(c->M + (c->M >> 3) + 2) * sizeof(double2);
+    if (ola) b += (size_t)c->W * sizeof(double);
+    return b;
+}
+
+inline int threads_for(const voc_ctx *c)
+{
+    int t = c->M / 8;
+    return t < 64 ? 64 : (t > 1024 ? 1024 : t);
+}
+
+#define VOC_FOR_EACH_LOG2M(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
+
+template <bool RAW, bool SPEC>
+void launch_analysis(voc_ctx *c, const voc::AnaArgs &a, long long channels, hipStream_t st)
+{
+    const long long grid = channels * a.tiles;
+    if (grid <= 0) return;
+    if (grid > 0x7fffffffLL) throw HipFail{hipErrorInvalidValue, "analysis grid too large"};
+    switch (c->log2m) {
+#define X(L)                                                                                              \
+    case L:                                                                                               \
+        hipLaunchKernelGGL((voc::analysis_kernel<L, RAW, SPEC>), dim3((unsigned)grid), dim3(voc::Cfg<L>::T), \
+                           lds_bytes(c, false), st, c->params, a);                                        \
+        break;
+        VOC_FOR_EACH_LOG2M(X)
+#undef X
+    }
+    HIPCHK(hipGetLastError());
+}
+
+template <int IN_MODE, int OUT_MODE>
+void launch_synthesis(voc_ctx *c, const voc::SynArgs &a, long long channels, hipStream_t st)
+{
+    const long long grid = channels * a.tiles;
+    if (grid <= 0) return;
+    if (grid > 0x7fffffffLL) throw HipFail{hipErrorInvalidValue, "synthesis grid too large"};
+    switch (c->log2m) {
+#define X(L)                                                                                                    \
+    case L:                                                                                                     \
+        hipLaunchKernelGGL((voc::synthesis_kernel<L, IN_MODE, OUT_MODE>), dim3((unsigned)grid), dim3(voc::Cfg<L>::T), \
+                           lds_bytes(c, OUT_MODE == voc::SYN_OUT_OLA), st, c->params, a);                       \
+        break;
+        VOC_FOR_EACH_LOG2M(X)
+#undef X
+    }
+    HIPCHK(hipGetLastError());
+}
+
+inline unsigned ew_grid(long long total)
+{
+    long long g = (total + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > 65536) g = 65536;
+    return (unsigned)g;
+}
+
+// Frames per analysis tile.  A tile recomputes the frame before its first one (to recover that
+// frame's raw phase), so long tiles are cheap; short ones keep small problems spread over the chip.
+int analysis_tile_len(const voc_ctx *c, long long channels, long long F)
+{
+    if (c->ana_tile_override > 0) return c->ana_tile_override;
+    long long tl = channels * F / 4096;
+    if (tl < 8) tl = 8;
+    if (tl > 64) tl = 64;
+    if (tl > F) tl = F;
+    return (int)(tl < 1 ? 1 : tl);
+}
+
+// Synthesis tiles per channel.  The phase chain is sequential along frames, so a channel is cut
+// only when there are too few channels to fill the chip; a cut costs one pass of the carry
+// kernel over ph_inc plus `halo` recomputed frames per tile in overlap-add mode.
+void synthesis_tiling(const voc_ctx *c, long long channels, long long F, int halo, int *tile_len, int *tiles)
+{
+    long long tl;
+    if (c->syn_tile_override > 0) {
+        tl = c->syn_tile_override;
+    } else {
+        long long want = (2048 + channels - 1) / channels;  // tiles per channel to reach ~2048 workgroups
+        long long min_tile = 8LL * (halo + 1);
+        if (min_tile < 16) min_tile = 16;
+        long long max_tiles = F / min_tile;
+        if (max_tiles < 1) max_tiles = 1;
+        if (want > max_tiles) want = max_tiles;
+        if (want < 1) want = 1;
+        tl = (F + want - 1) / want;
+    }
+    if (tl <= halo) tl = halo + 1;
+    if (tl > F) tl = F;
+    if (tl < 1) tl = 1;
+    *tile_len = (int)tl;
+    *tiles = (int)((F + tl - 1) / tl);
+}
+
+void ensure_ws(voc_ctx *c, size_t bytes)
+{
+    if (bytes <= c->ws_bytes) return;
+    if (c->ws) {
+        HIPCHK(hipDeviceSynchronize());
+        (void)hipFree(c->ws);
+        c->ws = nullptr;
+        c->ws_bytes = 0;
+    }
+    HIPCHK(hipMalloc(&c->ws, bytes));
+    c->ws_bytes = bytes;
+}
+
+inline long long num_frames(const voc_ctx *c, long long len) { return len < c->W ? 0 : (len - c->W) / c->H + 1; }
+
+inline long long ola_length(const voc_ctx *c, long long F, long long chunk)
+{
+    if (F <= 0) return 0;
+    const long long last = (F - 1) * c->H + c->W - 1;
+    return (last / chunk + 1) * chunk;
+}
+
+inline long long leftover_length(const voc_ctx *c, long long len)
+{
+    long long drop = floordiv(len - c->W, c->H) * c->H + c->H;
+    if (drop < 0) drop = 0;
+    if (drop > len) drop = len;
+    return len - drop;
+}
+
+// ---- device-pointer bodies (ctx->mu held, device set) -------------------------------------------
+
+void analysis_stage_dev(voc_ctx *c, double *phase_io, const double *frames, double *mag, double *inc, long long C,
+                        long long F, hipStream_t st)
+{
+    if (C <= 0 || F <= 0) return;
+    // the kernel reads the initial phases while another tile may already write the final ones
+    ensure_ws(c, (size_t)C * c->K * sizeof(double));
+    double *pin = static_cast<double *>(c->ws);
+    HIPCHK(hipMemcpyAsync(pin, phase_io, (size_t)C * c->K * sizeof(double), hipMemcpyDeviceToDevice, st));
+    voc::AnaArgs a{};
+    a.x = frames;
+    a.chan_stride = F * c->W;
+    a.frame_stride = c->W;
+    a.phase_in = pin;
+    a.phase_out = phase_io;
+    a.mag = mag;
+    a.inc = inc;
+    a.ldk = c->K;
+    a.F = F;
+    a.tile_len = analysis_tile_len(c, C, F);
+    a.tiles = (int)((F + a.tile_len - 1) / a.tile_len);
+    a.vol = 1.0;
+    launch_analysis<false, false>(c, a, C, st);
+}
+
+void synthesis_stage_dev(voc_ctx *c, double *phase_io, const double *mag, const double *inc, double *frames,
+                         long long C, long long F, hipStream_t st)
+{
+    if (C <= 0 || F <= 0) return;
+    int tile_len, tiles;
+    synthesis_tiling(c, C, F, 0, &tile_len, &tiles);
+    const size_t pin_bytes = (size_t)C * c->K * sizeof(double);
+    const size_t carry_bytes = tiles > 1 ? (size_t)C * tiles * c->K * sizeof(double) : 0;
+    ensure_ws(c, pin_bytes + carry_bytes);
+    double *pin = static_cast<double *>(c->ws);
+    double *carry = pin + (size_t)C * c->K;
+    HIPCHK(hipMemcpyAsync(pin, phase_io, pin_bytes, hipMemcpyDeviceToDevice, st));
+    if (tiles > 1) {
+        const long long chains = C * c->K;
+        hipLaunchKernelGGL(voc::phase_carry_kernel, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st,
+                           c->params, inc, (long long)c->K, F, pin, carry, tile_len, tiles, 0, C);
+        HIPCHK(hipGetLastError());
+    }
+    voc::SynArgs a{};
+    a.mag = mag;
+    a.inc = inc;
+    a.ldk = c->K;
+    a.phase_in = pin;
+    a.carry = carry;
+    a.phase_out = phase_io;
+    a.out = frames;
+    a.F = F;
+    a.tile_len = tile_len;
+    a.tiles = tiles;
+    a.halo = 0;
+    launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_FRAMES>(c, a, C, st);
+}
+
+struct RtPlan {
+    long long F, out_len, ldk;
+    int ana_tile, ana_tiles, syn_tile, syn_tiles, halo;
+    size_t per_channel_bytes;  // STFT + carry + two phase snapshots
+};
+
+RtPlan roundtrip_plan(const voc_ctx *c, long long len, long long group, long long chunk)
+{
+    RtPlan r{};
+    r.F = num_frames(c, len);
+    r.out_len = ola_length(c, r.F, chunk > 0 ? chunk : c->H);
+    r.ldk = (c->K + 1) & ~1LL;
+    r.halo = (c->W + c->H - 1) / c->H - 1;
+    if (r.F > 0) {
+        r.ana_tile = analysis_tile_len(c, group, r.F);
+        r.ana_tiles = (int)((r.F + r.ana_tile - 1) / r.ana_tile);
+        synthesis_tiling(c, group, r.F, r.halo, &r.syn_tile, &r.syn_tiles);
+    }
+    r.per_channel_bytes = (size_t)(2 * r.F * r.ldk + (long long)(r.syn_tiles > 1 ? r.syn_tiles : 0) * c->K + 2LL * c->K) *
+                          sizeof(double);
+    return r;
+}
+
+void roundtrip_dev(voc_ctx *c, const double *x, long long x_stride, long long len, long long C, long long chunk,
+                   double *y, long long y_stride, double *ana_phase, double *syn_phase, double *leftover,
+                   long long leftover_stride, void *ws, long long ws_bytes, hipStream_t st)
+{
+    if (C <= 0) return;
+    const long long F = num_frames(c, len);
+    const long long keep = leftover_length(c, len);
+    if (leftover && keep > 0)
+        HIPCHK(hipMemcpy2DAsync(leftover, (size_t)leftover_stride * sizeof(double), x + (len - keep),
+                                (size_t)x_stride * sizeof(double), (size_t)keep * sizeof(double), (size_t)C,
+                                hipMemcpyDeviceToDevice, st));
+    if (F <= 0) return;
+
+    // channels per pass: as many as the workspace holds
+    RtPlan full = roundtrip_plan(c, len, C, chunk);
+    long long group = C;
+    if (!ws) {
+        size_t cap = (size_t)160 << 30;
+        const int cap_gb = env_int("VOC_WS_CAP_GB");
+        if (cap_gb > 0) cap = (size_t)cap_gb << 30;
+        while (group > 1 && roundtrip_plan(c, len, group, chunk).per_channel_bytes * (size_t)group > cap)
+            group = (group + 1) / 2;
+        ensure_ws(c, roundtrip_plan(c, len, group, chunk).per_channel_bytes * (size_t)group);
+        ws = c->ws;
+    } else {
+        while (group > 1 && roundtrip_plan(c, len, group, chunk).per_channel_bytes * (size_t)group > (size_t)ws_bytes)
+            group = (group + 1) / 2;
+        if (roundtrip_plan(c, len, group, chunk).per_channel_bytes * (size_t)group > (size_t)ws_bytes)
+            throw HipFail{hipErrorInvalidValue, "workspace smaller than one channel needs"};
+    }
+    (void)full;
+
+    for (long long c0 = 0; c0 < C; c0 += group) {
+        const long long G = (C - c0 < group) ? C - c0 : group;
+        const RtPlan r = roundtrip_plan(c, len, group, chunk);
+        double *mag = static_cast<double *>(ws);
+        double *inc = mag + (size_t)G * F * r.ldk;
+        double *pinA = inc + (size_t)G * F * r.ldk;
+        double *pinS = pinA + (size_t)G * c->K;
+        double *carry = pinS + (size_t)G * c->K;
+        double *aph = ana_phase + c0 * c->K, *sph = syn_phase + c0 * c->K;
+        HIPCHK(hipMemcpyAsync(pinA, aph, (size_t)G * c->K * sizeof(double), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(pinS, sph, (size_t)G * c->K * sizeof(double), hipMemcpyDeviceToDevice, st));
+
+        voc::AnaArgs a{};
+        a.x = x + c0 * x_stride;
+        a.chan_stride = x_stride;
+        a.frame_stride = c->H;  // framing fused: frame j starts at sample j*H (Frames.hs:34-35)
+        a.phase_in = pinA;
+        a.phase_out = aph;
+        a.mag = mag;
+        a.inc = inc;
+        a.ldk = r.ldk;
+        a.F = F;
+        a.tile_len = r.ana_tile;
+        a.tiles = r.ana_tiles;
+        a.vol = c->vol;  // volumeFix folded into the magnitude store (Conduit.hs:34-35)
+        launch_analysis<false, false>(c, a, G, st);
+
+        if (r.syn_tiles > 1) {
+            const long long chains = G * c->K;
+            hipLaunchKernelGGL(voc::phase_carry_kernel, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st,
+                               c->params, inc, r.ldk, F, pinS, carry, r.syn_tile, r.syn_tiles, r.halo, G);
+            HIPCHK(hipGetLastError());
+        }
+        voc::SynArgs s{};
+        s.mag = mag;
+        s.inc = inc;
+        s.ldk = r.ldk;
+        s.phase_in = pinS;
+        s.carry = carry;
+        s.phase_out = sph;
+        s.out = y + c0 * y_stride;
+        s.out_stride = y_stride;
+        s.out_len = r.out_len;
+        s.F = F;
+        s.tile_len = r.syn_tile;
+        s.tiles = r.syn_tiles;
+        s.halo = r.halo;
+        launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_OLA>(c, s, G, st);
+    }
+}
+
+struct Locked {  // serialises calls on a context and pins its device for the calling thread
+    std::lock_guard<std::mutex> g;
+    explicit Locked(voc_ctx *c) : g(c->mu) { HIPCHK(hipSetDevice(c->device)); }
+};
+
+}  // namespace
+
+// ================================================================================ C ABI
+
+VOC_EXPORT const char *voc_strerror(int32_t s)
+{
+    switch (s) {
+    case VOC_OK: return "ok";
+    case VOC_ERR_INVALID: return "invalid argument";
+    case VOC_ERR_UNSUPPORTED: return "unsupported frame length or precision (frame length must be a power of two in [8, 16384])";
+    case VOC_ERR_HIP: return "HIP runtime call failed";
+    case VOC_ERR_NOMEM: return "out of memory";
+    case VOC_ERR_SIZE: return "size mismatch";
+    case VOC_ERR_NO_DEVICE: return "no usable GPU";
+    default: return "unknown status";
+    }
+}
+
+VOC_EXPORT const char *voc_last_hip_error(const voc_ctx *ctx) { return ctx ? ctx->hip_err.c_str() : ""; }
+
+VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, int32_t W, int32_t device,
+                                  int32_t precision, voc_ctx **out)
+{
+    if (!out) return VOC_ERR_INVALID;
+    *out = nullptr;
+    if (!window || W < 1 || H < 1 || N < 1) return VOC_ERR_INVALID;
+    if (W > N) return VOC_ERR_INVALID;  // addZeroPadding: input longer than target length (Vocoder.hs:132)
+    if (precision != VOC_PRECISION_F64) return VOC_ERR_UNSUPPORTED;
+    if (N < 8 || N > 16384 || (N & (N - 1)) != 0) return VOC_ERR_UNSUPPORTED;
+    voc_ctx *c = new (std::nothrow) voc_ctx;
+    if (!c) return VOC_ERR_NOMEM;
+    int32_t rc = guarded(c, [&]() -> int32_t {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return VOC_ERR_NO_DEVICE;
+        if (device < 0 || device >= ndev) return VOC_ERR_INVALID;
+        HIPCHK(hipSetDevice(device));
+        c->N = N; c->W = W; c->H = H; c->K = N / 2 + 1; c->M = N / 2; c->device = device;
+        c->log2m = 0;
+        while ((1 << c->log2m) < c->M) ++c->log2m;
+        c->window.assign(window, window + W);
+        // volumeCoeff = H / sum (map (**2) window), left fold from 0 (Vocoder.hs:209-210)
+        double s = 0.0;
+        for (int i = 0; i < W; ++i) s = s + std::pow(window[i], 2.0);
+        c->vol = (double)H / s;
+        c->ana_tile_override = env_int("VOC_ANA_TILE_LEN");
+        c->syn_tile_override = env_int("VOC_SYN_TILE_LEN");
+
+        std::vector<double2> twM((size_t)c->M), twS((size_t)c->M / 2 + 1);
+        const long double two_pi = 2.0L * 3.141592653589793238462643383279502884L;
+        for (int m = 0; m < c->M; ++m) {
+            const long double ang = two_pi * (long double)m / (long double)c->M;
+            twM[m] = make_double2((double)cosl(ang), (double)-sinl(ang));
+        }
+        for (int k = 0; k <= c->M / 2; ++k) {
+            const long double ang = two_pi * (long double)k / (long double)N;
+            twS[k] = make_double2((double)cosl(ang), (double)-sinl(ang));
+        }
+        HIPCHK(hipMalloc((void **)&c->d_window, sizeof(double) * (size_t)W));
+        HIPCHK(hipMalloc((void **)&c->d_twM, sizeof(double2) * twM.size()));
+        HIPCHK(hipMalloc((void **)&c->d_twS, sizeof(double2) * twS.size()));
+        HIPCHK(hipMemcpy(c->d_window, window, sizeof(double) * (size_t)W, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_twM, twM.data(), sizeof(double2) * twM.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_twS, twS.data(), sizeof(double2) * twS.size(), hipMemcpyHostToDevice));
+
+        voc::Params &p = c->params;
+        p.N = N; p.W = W; p.H = H; p.K = c->K; p.M = c->M;
+        const int diff = N - W;
+        p.hd = diff - diff / 2;
+        p.off = diff / 2;
+        p.hop_pow2 = (H & (H - 1)) == 0;
+        p.hop_d = (double)H;
+        p.inv_hop = 1.0 / (double)H;
+        p.inv_n = 1.0 / (double)N;
+        p.window = c->d_window;
+        p.twM = c->d_twM;
+        p.twS = c->d_twS;
+        return VOC_OK;
+    });
+    if (rc != VOC_OK) {
+        voc_ctx_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return VOC_OK;
+}
+
+VOC_EXPORT int32_t voc_ctx_destroy(voc_ctx *c)
+{
+    if (!c) return VOC_OK;
+    (void)hipSetDevice(c->device);
+    if (c->ws) { (void)hipDeviceSynchronize(); (void)hipFree(c->ws); }
+    if (c->d_window) (void)hipFree(c->d_window);
+    if (c->d_twM) (void)hipFree(c->d_twM);
+    if (c->d_twS) (void)hipFree(c->d_twS);
+    delete c;
+    return VOC_OK;
+}
+
+VOC_EXPORT int32_t voc_frame_length(const voc_ctx *c) { return c ? c->N : VOC_ERR_INVALID; }
+VOC_EXPORT int32_t voc_input_frame_length(const voc_ctx *c) { return c ? c->W : VOC_ERR_INVALID; }
+VOC_EXPORT int32_t voc_freq_frame_length(const voc_ctx *c) { return c ? c->K : VOC_ERR_INVALID; }
+VOC_EXPORT int32_t voc_hop_size(const voc_ctx *c) { return c ? c->H : VOC_ERR_INVALID; }
+VOC_EXPORT double voc_volume_coeff(const voc_ctx *c) { return c ? c->vol : 0.0; }
+VOC_EXPORT int32_t voc_window(const voc_ctx *c, double *out)
+{
+    if (!c || !out) return VOC_ERR_INVALID;
+    std::memcpy(out, c->window.data(), sizeof(double) * (size_t)c->W);
+    return VOC_OK;
+}
+
+VOC_EXPORT int64_t voc_num_frames(const voc_ctx *c, int64_t len) { return c ? num_frames(c, len) : VOC_ERR_INVALID; }
+VOC_EXPORT int64_t voc_leftover_length(const voc_ctx *c, int64_t len) { return c ? leftover_length(c, len) : VOC_ERR_INVALID; }
+VOC_EXPORT int64_t voc_ola_length(const voc_ctx *c, int64_t F, int64_t chunk)
+{
+    if (!c || chunk < 1) return VOC_ERR_INVALID;
+    return ola_length(c, F, chunk);
+}
+
+// ---- FFT-compatible layer ---------------------------------------------------------------------------
+
+namespace {
+template <bool RAW>
+int32_t spec_forward(voc_ctx *c, const double *in, double *out, int64_t B)
+{
+    if (!c || B < 0 || (B > 0 && (!in || !out))) return VOC_ERR_INVALID;
+    if (B == 0) return VOC_OK;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c);
+        const size_t in_len = RAW ? (size_t)c->N : (size_t)c->W;
+        DevBuf din((size_t)B * in_len * sizeof(double)), dout((size_t)B * c->K * 2 * sizeof(double));
+        HIPCHK(hipMemcpy(din.p, in, (size_t)B * in_len * sizeof(double), hipMemcpyHostToDevice));
+        voc::AnaArgs a{};
+        a.x = din.d();
+        a.chan_stride = 0;
+        a.frame_stride = (long long)in_len;
+        a.spec = dout.d();
+        a.F = B;
+        a.tile_len = 4;
+        a.tiles = (int)((B + 3) / 4);
+        a.vol = 1.0;
+        launch_analysis<RAW, true>(c, a, 1, nullptr);
+        HIPCHK(hipMemcpy(out, dout.p, (size_t)B * c->K * 2 * sizeof(double), hipMemcpyDeviceToHost));
+        return VOC_OK;
+    });
+}
+
+template <int OUT_MODE>
+int32_t spec_backward(voc_ctx *c, const double *in, double *out, int64_t B)
+{
+    if (!c || B < 0 || (B > 0 && (!in || !out))) return VOC_ERR_INVALID;
+    if (B == 0) return VOC_OK;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c);
+        const size_t out_len = OUT_MODE == voc::SYN_OUT_RAW ? (size_t)c->N : (size_t)c->W;
+        DevBuf din((size_t)B * c->K * 2 * sizeof(double)), dout((size_t)B * out_len * sizeof(double));
+        HIPCHK(hipMemcpy(din.p, in, (size_t)B * c->K * 2 * sizeof(double), hipMemcpyHostToDevice));
+        voc::SynArgs a{};
+        a.spec = din.d();
+        a.out = dout.d();
+        a.F = B;
+        a.tile_len = 4;
+        a.tiles = (int)((B + 3) / 4);
+        launch_synthesis<voc::SYN_IN_SPEC, OUT_MODE>(c, a, 1, nullptr);
+        HIPCHK(hipMemcpy(out, dout.p, (size_t)B * out_len * sizeof(double), hipMemcpyDeviceToHost));
+        return VOC_OK;
+    });
+}
+}  // namespace
+
+VOC_EXPORT int32_t voc_r2c(voc_ctx *c, const double *in, double *out, int64_t B) { return spec_forward<true>(c, in, out, B); }
+VOC_EXPORT int32_t voc_do_fft(voc_ctx *c, const double *fr, double *spec, int64_t B) { return spec_forward<false>(c, fr, spec, B); }
+VOC_EXPORT int32_t voc_c2r(voc_ctx *c, const double *in, double *out, int64_t B) { return spec_backward<voc::SYN_OUT_RAW>(c, in, out, B); }
+VOC_EXPORT int32_t voc_do_ifft(voc_ctx *c, const double *spec, double *fr, int64_t B) { return spec_backward<voc::SYN_OUT_FRAMES>(c, spec, fr, B); }
+
+// ---- step level ---------------------------------------------------------------------------------------
+
+VOC_EXPORT int32_t voc_analysis_step(voc_ctx *c, const double *prev_ph, const double *spec, double *ph_out, double *mag,
+                                     double *ph_inc, int64_t B)
+{
+    if (!c || B < 0 || (B > 0 && (!prev_ph || !spec || !ph_out || !mag || !ph_inc))) return VOC_ERR_INVALID;
+    if (B == 0) return VOC_OK;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c);
+        const size_t n = (size_t)B * c->K, nb = n * sizeof(double);
+        DevBuf dprev(nb), dspec(2 * nb), dph(nb), dmag(nb), dinc(nb);
+        HIPCHK(hipMemcpy(dprev.p, prev_ph, nb, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dspec.p, spec, 2 * nb, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(voc::analysis_step_kernel, dim3(ew_grid((long long)n)), dim3(256), 0, nullptr, c->params,
+                           dprev.d(), dspec.d(), dph.d(), dmag.d(), dinc.d(), (long long)n);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(ph_out, dph.p, nb, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(mag, dmag.p, nb, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ph_inc, dinc.p, nb, hipMemcpyDeviceToHost));
+        return VOC_OK;
+    });
+}
+
+VOC_EXPORT int32_t voc_synthesis_step(voc_ctx *c, const double *ph, const double *mag, const double *ph_inc,
+                                      double *ph_out, double *spec, int64_t B)
+{
+    if (!c || B < 0 || (B > 0 && (!ph || !mag || !ph_inc || !ph_out || !spec))) return VOC_ERR_INVALID;
+    if (B == 0) return VOC_OK;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c);
+        const size_t n = (size_t)B * c->K, nb = n * sizeof(double);
+        DevBuf dph(nb), dmag(nb), dinc(nb), dout(nb), dspec(2 * nb);
+        HIPCHK(hipMemcpy(dph.p, ph, nb, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dmag.p, mag, nb, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dinc.p, ph_inc, nb, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(voc::synthesis_step_kernel, dim3(ew_grid((long long)n)), dim3(256), 0, nullptr, c->params,
+                           dph.d(), dmag.d(), dinc.d(), dout.d(), dspec.d(), (long long)n);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(ph_out, dout.p, nb, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(spec, dspec.p, 2 * nb, hipMemcpyDeviceToHost));
+        return VOC_OK;
+    });
+}
+
+VOC_EXPORT int32_t voc_add_frames(voc_ctx *c, const double *mag1, const double *inc1, const double *mag2,
+                                  const double *inc2, double *mag_out, double *inc_out, int64_t B)
+{
+    if (!c || B < 0 || (B > 0 && (!mag1 || !inc1 || !mag2 || !inc2 || !mag_out || !inc_out))) return VOC_ERR_INVALID;
+    if (B == 0) return VOC_OK;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c);
+        const size_t n = (size_t)B * c->K, nb = n * sizeof(double);
+        DevBuf a(nb), b(nb), d(nb), e(nb), mo(nb), io(nb);
+        HIPCHK(hipMemcpy(a.p, mag1, nb, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(b.p, inc1, nb, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d.p, mag2, nb, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e.p, inc2, nb, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(voc::add_frames_kernel, dim3(ew_grid((long long)n)), dim3(256), 0, nullptr, a.d(), b.d(),
+                           d.d(), e.d(), mo.d(), io.d(), (long long)n);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(mag_out, mo.p, nb, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(inc_out, io.p, nb, hipMemcpyDeviceToHost));
+        return VOC_OK;
+    });
+}
+
+// ---- stage level ------------------------------------------------------------------------------------------
+
+VOC_EXPORT int32_t voc_analysis_stage_dev(voc_ctx *c, double *phase_io, const double *frames, double *mag,
+                                          double *ph_inc, int64_t C, int64_t F, void *stream)
+{
+    if (!c || C < 0 || F < 0) return VOC_ERR_INVALID;
+    if (C > 0 && F > 0 && (!phase_io || !frames || !mag || !ph_inc)) return VOC_ERR_INVALID;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c);
+        analysis_stage_dev(c, phase_io, frames, mag, ph_inc, C, F, (hipStream_t)stream);
+        return VOC_OK;
+    });
+}
+
+VOC_EXPORT int32_t voc_synthesis_stage_dev(voc_ctx *c, double *phase_io, const double *mag, const double *ph_inc,
+                                           double *frames, int64_t C, int64_t F, void *stream)
+{
+    if (!c || C < 0 || F < 0) return VOC_ERR_INVALID;
+    if (C > 0 && F > 0 && (!phase_io || !frames || !mag || !ph_inc)) return VOC_ERR_INVALID;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c);
+        synthesis_stage_dev(c, phase_io, mag, ph_inc, frames, C, F, (hipStream_t)stream);
+        return VOC_OK;
+    });
+}
+
+VOC_EXPORT int32_t voc_analysis_stage(voc_ctx *c, double *phase_io, const double *frames, double *mag, double *ph_inc,
+                                      int64_t C, int64_t F)
+{
+    if (!c || C < 0 || F < 0) return VOC_ERR_INVALID;
+    if (C == 0 || F == 0) return VOC_OK;  // mapAccumL over no frames returns the phase unchanged
+    if (!phase_io || !frames || !mag || !ph_inc) return VOC_ERR_INVALID;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c);
+        const size_t nph = (size_t)C * c->K * sizeof(double), nfr = (size_t)C * F * c->W * sizeof(double),
+                     nst = (size_t)C * F * c->K * sizeof(double);
+        DevBuf dph(nph), dfr(nfr), dmag(nst), dinc(nst);
+        HIPCHK(hipMemcpy(dph.p, phase_io, nph, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dfr.p, frames, nfr, hipMemcpyHostToDevice));
+        analysis_stage_dev(c, dph.d(), dfr.d(), dmag.d(), dinc.d(), C, F, nullptr);
+        HIPCHK(hipMemcpy(phase_io, dph.p, nph, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(mag, dmag.p, nst, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ph_inc, dinc.p, nst, hipMemcpyDeviceToHost));
+        return VOC_OK;
+    });
+}
+
+VOC_EXPORT int32_t voc_synthesis_stage(voc_ctx *c, double *phase_io, const double *mag, const double *ph_inc,
+                                       double *frames, int64_t C, int64_t F)
+{
+    if (!c || C < 0 || F < 0) return VOC_ERR_INVALID;
+    if (C == 0 || F == 0) return VOC_OK;
+    if (!phase_io || !frames || !mag || !ph_inc) return VOC_ERR_INVALID;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c);
+        const size_t nph = (size_t)C * c->K * sizeof(double), nfr = (size_t)C * F * c->W * sizeof(double),
+                     nst = (size_t)C * F * c->K * sizeof(double);
+        DevBuf dph(nph), dfr(nfr), dmag(nst), dinc(nst);
+        HIPCHK(hipMemcpy(dph.p, phase_io, nph, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dmag.p, mag, nst, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dinc.p, ph_inc, nst, hipMemcpyHostToDevice));
+        synthesis_stage_dev(c, dph.d(), dmag.d(), dinc.d(), dfr.d(), C, F, nullptr);
+        HIPCHK(hipMemcpy(phase_io, dph.p, nph, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(frames, dfr.p, nfr, hipMemcpyDeviceToHost));
+        return VOC_OK;
+    });
+}
+
+// ---- framing and overlap-add --------------------------------------------------------------------------------
+
+VOC_EXPORT int32_t voc_frames_of(voc_ctx *c, const double *x, int64_t x_stride, int64_t len, int64_t C, double *frames)
+{
+    if (!c || C < 0 || len < 0 || x_stride < len) return VOC_ERR_INVALID;
+    const long long F = c ? num_frames(c, len) : 0;
+    if (C == 0 || F == 0) return VOC_OK;
+    if (!x || !frames) return VOC_ERR_INVALID;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c);
+        const size_t nx = (size_t)C * x_stride * sizeof(double), nfr = (size_t)C * F * c->W * sizeof(double);
+        DevBuf dx(nx), dfr(nfr);
+        HIPCHK(hipMemcpy(dx.p, x, nx, hipMemcpyHostToDevice));
+        const long long total = C * F * c->W;
+        hipLaunchKernelGGL(voc::frames_of_kernel, dim3(ew_grid(total)), dim3(256), 0, nullptr, dx.d(),
+                           (long long)x_stride, dfr.d(), F, c->W, c->H, total);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(frames, dfr.p, nfr, hipMemcpyDeviceToHost));
+        return VOC_OK;
+    });
+}
+
+VOC_EXPORT int32_t voc_sum_frames(voc_ctx *c, const double *frames, int64_t F, int64_t C, int64_t chunk, double *y,
+                                  int64_t y_stride)
+{
+    if (!c || C < 0 || F < 0 || chunk < 1) return VOC_ERR_INVALID;
+    const long long out_len = ola_length(c, F, chunk);
+    if (C == 0 || F == 0) return VOC_OK;
+    if (!frames || !y || y_stride < out_len) return VOC_ERR_INVALID;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c);
+        const size_t nfr = (size_t)C * F * c->W * sizeof(double), ny = (size_t)C * y_stride * sizeof(double);
+        DevBuf dfr(nfr), dy(ny);
+        HIPCHK(hipMemcpy(dfr.p, frames, nfr, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dy.p, y, ny, hipMemcpyHostToDevice));  // keeps the caller's bytes between rows
+        const long long total = C * out_len;
+        hipLaunchKernelGGL(voc::sum_frames_kernel, dim3(ew_grid(total)), dim3(256), 0, nullptr, dfr.d(), (long long)F,
+                           c->W, c->H, dy.d(), (long long)y_stride, out_len, total);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(y, dy.p, ny, hipMemcpyDeviceToHost));
+        return VOC_OK;
+    });
+}
+
+// ---- fused round trip -----------------------------------------------------------------------------------------
+
+VOC_EXPORT int64_t voc_roundtrip_workspace_bytes(const voc_ctx *c, int64_t len, int64_t C)
+{
+    if (!c || len < 0 || C < 0) return VOC_ERR_INVALID;
+    if (C == 0) return 0;
+    return (int64_t)(roundtrip_plan(c, len, C, c->H).per_channel_bytes * (size_t)C);
+}
+
+VOC_EXPORT int32_t voc_roundtrip_dev(voc_ctx *c, const double *x, int64_t x_stride, int64_t len, int64_t C,
+                                     int64_t chunk, double *y, int64_t y_stride, double *ana_phase_io,
+                                     double *syn_phase_io, double *leftover, int64_t leftover_stride, void *workspace,
+                                     int64_t workspace_bytes, void *stream)
+{
+    if (!c || C < 0 || len < 0 || chunk < 1 || x_stride < len) return VOC_ERR_INVALID;
+    if (C == 0) return VOC_OK;
+    const long long F = num_frames(c, len);
+    if (!x || !ana_phase_io || !syn_phase_io) return VOC_ERR_INVALID;
+    if (F > 0 && (!y || y_stride < ola_length(c, F, chunk))) return VOC_ERR_SIZE;
+    if (leftover && leftover_stride < leftover_length(c, len)) return VOC_ERR_SIZE;
+    if (workspace && workspace_bytes < 0) return VOC_ERR_INVALID;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c);
+        roundtrip_dev(c, x, x_stride, len, C, chunk, y, y_stride, ana_phase_io, syn_phase_io, leftover,
+                      leftover_stride, workspace, workspace_bytes, (hipStream_t)stream);
+        return VOC_OK;
+    });
+}
+
+VOC_EXPORT int32_t voc_roundtrip(voc_ctx *c, const double *x, int64_t x_stride, int64_t len, int64_t C, int64_t chunk,
+                                 double *y, int64_t y_stride, double *ana_phase_io, double *syn_phase_io,
+                                 double *leftover, int64_t leftover_stride)
+{
+    if (!c || C < 0 || len < 0 || chunk < 1 || x_stride < len) return VOC_ERR_INVALID;
+    if (C == 0) return VOC_OK;
+    const long long F = num_frames(c, len), out_len = ola_length(c, F, chunk), keep = leftover_length(c, len);
+    if (!x || !ana_phase_io || !syn_phase_io) return VOC_ERR_INVALID;
+    if (F > 0 && (!y || y_stride < out_len)) return VOC_ERR_SIZE;
+    if (leftover && leftover_stride < keep) return VOC_ERR_SIZE;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c);
+        const size_t nx = (size_t)C * len * sizeof(double), ny = (size_t)C * out_len * sizeof(double),
+                     nph = (size_t)C * c->K * sizeof(double), nl = (size_t)C * keep * sizeof(double);
+        DevBuf dx(nx), dy(ny), da(nph), ds(nph), dl(nl);
+        HIPCHK(hipMemcpy2DAsync(dx.p, (size_t)len * sizeof(double), x, (size_t)x_stride * sizeof(double),
+                                (size_t)len * sizeof(double), (size_t)C, hipMemcpyHostToDevice, nullptr));
+        HIPCHK(hipMemcpy(da.p, ana_phase_io, nph, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ds.p, syn_phase_io, nph, hipMemcpyHostToDevice));
+        roundtrip_dev(c, dx.d(), len, len, C, chunk, dy.d(), out_len, da.d(), ds.d(), leftover ? dl.d() : nullptr, keep,
+                      nullptr, 0, nullptr);
+        HIPCHK(hipStreamSynchronize(nullptr));
+        if (out_len > 0)
+            HIPCHK(hipMemcpy2DAsync(y, (size_t)y_stride * sizeof(double), dy.p, (size_t)out_len * sizeof(double),
+                                    (size_t)out_len * sizeof(double), (size_t)C, hipMemcpyDeviceToHost, nullptr));
+        if (leftover && keep > 0)
+            HIPCHK(hipMemcpy2DAsync(leftover, (size_t)leftover_stride * sizeof(double), dl.p, (size_t)keep * sizeof(double),
+                                    (size_t)keep * sizeof(double), (size_t)C, hipMemcpyDeviceToHost, nullptr));
+        HIPCHK(hipMemcpy(ana_phase_io, da.p, nph, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(syn_phase_io, ds.p, nph, hipMemcpyDeviceToHost));
+        return VOC_OK;
+    });
+}
