@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py -- STFT analysis+synthesis round-trip throughput on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the fused round trip (framing, window, R2C FFT, phase analysis, volume fix,
+phase accumulation, polar synthesis, C2R IFFT, window, overlap-add) over the batch of the metric
+configuration: 1024 mono streams x 60 s at 48 kHz per GPU, N = W = 4096, H = 1024, fp64, identity
+filter, Hann window, synthetic signals generated in HBM before the timed region.  With N > 1 the
+script is started once per GPU by torch.distributed.run; streams are independent, so every rank
+owns its own 1024 streams and there is no collective on the data path (weak scaling).
+
+Rank 0 prints one JSON line.  `roofline` is for the slower of the two kernels of a step, its
+duration measured with HIP events on the launch stream; `cpu_baseline` times the CPU oracle (a C
+restatement of the reference, one core) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+N_FFT, HOP, RATE, SECONDS = 4096, 1024, 48000, 60
+HBM_PEAK = 8.0e12                                  # B/s, MI355X HBM3E
+K_BINS = N_FFT // 2 + 1
+BYTES_ANALYSIS = 8 * HOP + 16 * K_BINS             # unique input samples in, (mag, ph_inc) out
+BYTES_SYNTHESIS = 16 * K_BINS + 8 * HOP            # (mag, ph_inc) in, unique output samples out
+BYTES_FRAME = BYTES_ANALYSIS + BYTES_SYNTHESIS     # 81 952 B: the algorithmic bytes of one frame
+
+
+def make_streams(c, length, dev, rank):
+    """x_s[n] = 0.5 sin(2 pi f_s n / 48000 + theta_s) + 1e-2 u_s[n], f_s = 110 * 2^((s mod 72)/12) Hz."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x5EED + rank)
+    n = torch.arange(length, dtype=torch.float64, device=dev)
+    s = torch.arange(c, device=dev) + rank * c
+    f = 110.0 * torch.pow(2.0, (s % 72).double() / 12.0)
+    theta = torch.rand(c, generator=g, dtype=torch.float64, device=dev) * (2 * np.pi)
+    x = torch.empty(c, length, dtype=torch.float64, device=dev)
+    for lo in range(0, c, 32):
+        hi = min(c, lo + 32)
+        x[lo:hi] = 0.5 * torch.sin((2 * np.pi / RATE) * f[lo:hi, None] * n[None, :] + theta[lo:hi, None])
+        x[lo:hi] += 1e-2 * (2 * torch.rand(hi - lo, length, generator=g, dtype=torch.float64, device=dev) - 1)
+    return x
+
+
+def cpu_baseline(window, x_sample):
+    """The CPU oracle (C restatement of the reference's path, -O2, no FMA contraction) on one core."""
+    import oracle
+    oracle.build()
+    t0 = time.perf_counter()
+    frames = 0
+    for row in x_sample:
+        frames += oracle.roundtrip(N_FFT, HOP, window, row)["nframes"]
+    dt = time.perf_counter() - t0
+    return frames / dt, frames, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=1024, help="streams per GPU (metric configuration: 1024)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-streams", type=int, default=6, help="streams of the workload the CPU oracle is timed on")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from vocoder_amd import vocoder as V, conduit as Cd, window as Wn
+    win = Wn.hann_window(N_FFT)
+    par = V.VocoderParams(N_FFT, HOP, win, device=local_rank)
+    c, length = args.streams, RATE * SECONDS
+    frames_per_stream = Cd.num_frames(par, length)
+    frames = c * frames_per_stream
+    x = make_streams(c, length, dev, rank)
+    y = torch.empty(c, Cd.ola_length(par, frames_per_stream, HOP), dtype=torch.float64, device=dev)
+    aph = torch.zeros(c, par.K, dtype=torch.float64, device=dev)
+    sph = torch.zeros_like(aph)
+    ws = torch.empty(Cd.roundtrip_workspace_bytes(par, length, c), dtype=torch.uint8, device=dev)
+
+    def step():
+        Cd.process_dev(par, x, y, aph, sph, workspace=ws)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        aph.zero_(); sph.zero_()
+        step()
+    fence()
+    par.lib.check(par.lib.dll.voc_profile_enable(par.handle, 1))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    ms = (np.zeros(4), np.zeros(4, dtype=np.int64))
+    par.lib.check(par.lib.dll.voc_profile_read(par.handle, ms[0].ctypes.data, ms[1].ctypes.data))
+    par.lib.check(par.lib.dll.voc_profile_enable(par.handle, 0))
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    if rank == 0:
+        value = frames * world * args.steps / dt
+        names = ("analysis_kernel", "phase_carry_kernel", "synthesis_kernel")
+        avg = [ms[0][i] / ms[1][i] if ms[1][i] else 0.0 for i in range(3)]     # ms per launch
+        dom = 0 if avg[0] >= avg[2] else 2
+        alg = (BYTES_ANALYSIS, 0, BYTES_SYNTHESIS)[dom] * frames               # bytes one launch moves
+        achieved = alg / (avg[dom] * 1e-3) / 1e9 if avg[dom] else 0.0
+        out = {
+            "metric": "STFT frames/sec analysis+synthesis (N=4096,hop=1024,fp64); % HBM roofline",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "1024 mono synthetic streams x 60 s @48 kHz per GPU, N=W=4096 hop=1024 fp64 "
+                                   "identity round-trip (Hann), configs[1]",
+                       "streams_per_gpu": c, "frames_per_step_per_gpu": frames, "sharding": "by stream, no collective"},
+            "hbm_roofline_frac_whole_path": value / world * BYTES_FRAME / HBM_PEAK,
+            "kernel_ms": {names[i]: avg[i] for i in range(3) if ms[1][i]},
+            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9), "traffic": None},
+        }
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, if collected
+        if os.path.exists(tfile):
+            try:
+                out["roofline"]["traffic"] = json.load(open(tfile)).get(names[dom])
+            except Exception:
+                pass
+        if world == 1 and not args.no_cpu_baseline:
+            ncpu = min(args.cpu_streams, c)
+            v, nfr, secs = cpu_baseline(win, x[:ncpu].cpu().numpy())
+            out["cpu_baseline"] = {"value": v, "unit": "frames/s", "cores": 1, "kind": "port",
+                                   "sample": f"{ncpu} of the {c} streams x 60 s ({nfr} frames, {secs:.1f} s of CPU time), "
+                                             "C restatement of the reference path"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

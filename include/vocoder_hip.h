@@ -161,6 +161,15 @@ int32_t voc_roundtrip_dev(voc_ctx *ctx, const double *x, int64_t x_stride, int64
                           double *leftover, int64_t leftover_stride, void *workspace, int64_t workspace_bytes,
                           void *stream);
 
+/* ---- measurement hook (no counterpart in the reference) ------------------------------------------
+ * With profiling on, every kernel launch made through the context is bracketed by HIP events
+ * on its launch stream.  voc_profile_read waits for them, adds the elapsed milliseconds and
+ * launch counts per kernel kind into ms[4] / launches[4] -- 0: analysis kernel, 1: phase-carry
+ * kernel, 2: synthesis kernel, 3: FFT-only kernels -- and forgets them.
+ */
+int32_t voc_profile_enable(voc_ctx *ctx, int32_t on);
+int32_t voc_profile_read(voc_ctx *ctx, double *ms, int64_t *launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,19 +63,31 @@ static void fft_pow2(int n, double *re, double *im, int sign)
             t = im[i]; im[i] = im[j]; im[j] = t;
         }
     }
-    /* twiddles exp(sign * 2 pi i k / n), k < n/2, rounded from long double */
-    tw_re = (double *)malloc(sizeof(double) * (size_t)(n / 2 + 1));
-    tw_im = (double *)malloc(sizeof(double) * (size_t)(n / 2 + 1));
-    for (i = 0; i < n / 2; i++) {
-        long double a = 2.0L * 3.141592653589793238462643383279502884L * (long double)i / (long double)n;
-        tw_re[i] = (double)cosl(a);
-        tw_im[i] = (double)(sign < 0 ? -sinl(a) : sinl(a));
+    /* twiddles exp(sign * 2 pi i k / n), k < n/2, rounded from long double; the table of
+     * the last size used is kept (an FFT plan would hold it) */
+    {
+        static int cached_n = 0;
+        static double *c_re = NULL, *c_im = NULL;
+        if (cached_n != n) {
+            free(c_re);
+            free(c_im);
+            c_re = (double *)malloc(sizeof(double) * (size_t)(n / 2 + 1));
+            c_im = (double *)malloc(sizeof(double) * (size_t)(n / 2 + 1));
+            for (i = 0; i < n / 2; i++) {
+                long double a = 2.0L * 3.141592653589793238462643383279502884L * (long double)i / (long double)n;
+                c_re[i] = (double)cosl(a);
+                c_im[i] = (double)-sinl(a);
+            }
+            cached_n = n;
+        }
+        tw_re = c_re;
+        tw_im = c_im;
     }
     for (len = 2; len <= n; len <<= 1) {
         int half = len >> 1, step = n / len;
         for (i = 0; i < n; i += len) {
             for (j = 0; j < half; j++) {
-                double wr = tw_re[j * step], wi = tw_im[j * step];
+                double wr = tw_re[j * step], wi = sign < 0 ? tw_im[j * step] : -tw_im[j * step];
                 double xr = re[i + j + half], xi = im[i + j + half];
                 double tr = xr * wr - xi * wi;
                 double ti = xr * wi + xi * wr;
@@ -86,8 +98,6 @@ static void fft_pow2(int n, double *re, double *im, int sign)
             }
         }
     }
-    free(tw_re);
-    free(tw_im);
 }
 
 /* Direct O(n^2) DFT with long-double accumulation, any n. */

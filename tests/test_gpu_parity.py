@@ -1,0 +1,210 @@
+"""Parity of the HIP path against the oracle, through the C ABI, on a real MI355X.
+
+Bars (fp64): relative L2 <= 1e-9 on output samples, <= 1e-9 rad on wrapped phases (bins with
+magnitude >= 1e-5 of the frame's maximum; the phase of a noise-floor bin is not reproducible
+across FFT implementations), magnitudes <= 1e-9 relative.  Given identical STFT input the
+synthesis phase chain is required to match the oracle BIT FOR BIT.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import helpers as Hh
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("n,w,h", [(8, 8, 2), (16, 12, 4), (64, 64, 16), (256, 200, 64), (1024, 1024, 256),
+                                   (2048, 2048, 512), (4096, 4096, 1024), (4096, 3000, 1000), (8192, 8192, 2048),
+                                   (16384, 16384, 4096)])
+def test_fft_layer(gpu_lib, orc, n, w, h):
+    Hh.check_fft_layer(gpu_lib, orc, n, w, h, np.random.default_rng(n))
+
+
+@pytest.mark.parametrize("n,w,h,f,c,at,st,kind", [
+    (64, 64, 16, 9, 2, 0, 0, "noise"),
+    (64, 48, 16, 23, 2, 4, 5, "noise"),
+    (128, 100, 30, 17, 1, 3, 7, "noise"),
+    (64, 64, 64, 7, 1, 2, 3, "noise"),
+    (2048, 2048, 512, 40, 2, 0, 0, "tone"),        # config 1 shape
+    (4096, 4096, 1024, 48, 3, 0, 0, "tone"),       # metric shape, default tiling
+    (4096, 4096, 1024, 48, 2, 7, 11, "tone"),      # metric shape, forced multi-tile + carries
+    (8192, 8192, 2048, 12, 2, 0, 5, "tone"),       # config 3 shape
+    (16384, 12000, 3000, 6, 1, 0, 0, "noise"),
+])
+def test_stages(gpu_lib, orc, n, w, h, f, c, at, st, kind):
+    Hh.check_stages(gpu_lib, orc, n, w, h, f, c, np.random.default_rng(1), ana_tile=at, syn_tile=st, kind=kind)
+
+
+@pytest.mark.parametrize("n,w,h,length,c,at,st,chunk,kind", [
+    (64, 64, 16, 64 + 16 * 12 + 5, 2, 0, 0, None, "noise"),
+    (64, 48, 16, 48 + 16 * 22 + 3, 2, 4, 5, 48, "noise"),
+    (64, 32, 40, 32 + 40 * 8, 1, 2, 4, None, "noise"),         # hop > window
+    (128, 128, 32, 100, 2, 0, 0, None, "noise"),               # no full frame: leftover only
+    (128, 128, 32, 128, 1, 0, 0, 50, "noise"),                 # exactly one frame, ragged chunk
+    (256, 256, 1, 300, 1, 0, 0, None, "noise"),                # hop 1 (halo 255)
+    (2048, 2048, 512, 48000, 1, 0, 0, None, "tone"),           # config 1 shape, 1 s
+    (4096, 4096, 1024, 96000, 4, 0, 0, None, "tone"),          # metric shape, 2 s, 4 streams
+    (4096, 4096, 1024, 60000, 2, 9, 13, 1024, "tone"),         # metric shape, tiles + halo + carries
+    (4096, 2500, 700, 40000, 2, 0, 16, 4096, "tone"),          # padded frames, chunk = N
+    (8192, 8192, 2048, 60000, 2, 0, 0, None, "tone"),
+    (16384, 16384, 4096, 80000, 1, 0, 0, None, "noise"),       # overlap-add ring too large for LDS
+])
+def test_roundtrip(gpu_lib, orc, n, w, h, length, c, at, st, chunk, kind):
+    Hh.check_roundtrip(gpu_lib, orc, n, w, h, length, c, np.random.default_rng(2), ana_tile=at, syn_tile=st,
+                       chunk=chunk, kind=kind)
+
+
+ROUNDTRIPS = sorted(glob.glob(os.path.join(HERE, "golden", "roundtrip_*.npz")))
+
+
+@pytest.mark.parametrize("path", ROUNDTRIPS, ids=[os.path.basename(p)[10:-4] for p in ROUNDTRIPS])
+def test_golden_fixtures(gpu_lib, path):
+    from vocoder_amd import vocoder as V, conduit as Cd
+    g = np.load(path)
+    par = V.VocoderParams(int(g["N"]), int(g["H"]), g["window"], lib=gpu_lib)
+    y, left, (aph, sph) = Cd.process_with(par, g["x"], phases=(g["ana_phase_in"], g["syn_phase_in"]))
+    assert y.shape == g["y"].shape and np.array_equal(left, g["leftover"])
+    assert Hh.rel_l2(y, g["y"]) <= Hh.TOL_L2
+    big = g["mag"][-1] >= 0  # fixtures are tone + noise: every bin is above the noise floor gate
+    assert Hh.circ_dist(aph, g["ana_phase_out"])[big].max() <= Hh.TOL_PHASE
+    assert Hh.circ_dist(sph, g["syn_phase_out"]).max() <= 1e-8
+    par.close()
+
+
+def test_steps_framing_and_ola(gpu_lib, orc):
+    from vocoder_amd import vocoder as V, conduit as Cd
+    rng = np.random.default_rng(3)
+    n, w, h = 1024, 800, 200
+    win = orc.make_window("hamming", w)
+    par = V.VocoderParams(n, h, win, lib=gpu_lib)
+    k = par.K
+    spec = rng.standard_normal((5, k)) + 1j * rng.standard_normal((5, k))
+    spec[0, 3] = 0.0                      # phase (0 :+ 0) = 0
+    spec[1, 0] = -2.0 + 0.0j              # atan2 (+0) (-2) = pi
+    prev = rng.uniform(-3, 3, (5, k))
+    ph, (mag, inc) = V.analysis_step(par, prev, spec)
+    for b in range(5):
+        rp, rm, ri = orc.analysis_step(h, n, prev[b], spec[b])
+        assert np.abs(mag[b] - rm).max() <= 1e-15 * rm.max()
+        assert Hh.circ_dist(ph[b], rp).max() <= Hh.TOL_PHASE and Hh.circ_dist(inc[b] * h, ri * h).max() <= Hh.TOL_PHASE
+    assert ph[0, 3] == 0.0 and ph[1, 0] == np.pi
+    nph, sp = V.synthesis_step(par, prev, (mag, inc))
+    for b in range(5):
+        rp, rs = orc.synthesis_step(h, prev[b], mag[b], inc[b])
+        assert np.array_equal(nph[b], rp) and Hh.rel_l2(sp[b], rs) <= Hh.TOL_L2
+    m2, i2 = V.add_frames(par, (mag, inc), (mag[::-1], inc[::-1]))
+    for b in range(5):
+        rm, ri = orc.add_frames(mag[b], inc[b], mag[4 - b], inc[4 - b])
+        assert Hh.rel_l2(m2[b], rm) <= Hh.TOL_L2
+        assert Hh.circ_dist(i2[b], ri)[rm > 1e-9 * rm.max()].max() <= Hh.TOL_PHASE
+    x = rng.standard_normal((3, 5000))
+    frames, left = Cd.frames_of_e(par, x)
+    for ch in range(3):
+        rf, rl = orc.gen_frames_of_e(w, h, [x[ch]])
+        assert np.array_equal(frames[ch], rf) and np.array_equal(left[ch], rl)     # bit exact: pure data movement
+    for chunk in (h, 7, 1000):
+        y = Cd.sum_frames_e(par, frames, chunk)
+        for ch in range(3):
+            assert np.array_equal(y[ch], orc.sum_frames_e(chunk, h, list(frames[ch])).ravel())  # same summation order
+    assert V.volume_coeff(par) == orc.volume_coeff(h, win)
+    assert np.array_equal(V.voc_window(par), win)
+    par.close()
+
+
+def test_integer_framing_fixture_through_the_library(gpu_lib):
+    """Framing and overlap-add move / add values without rounding when they are small integers:
+    the library must reproduce the reference's list-model vectors exactly."""
+    from vocoder_amd import vocoder as V, conduit as Cd
+    g = np.load(os.path.join(HERE, "golden", "framing_int.npz"))
+    data = g["data"].astype(np.float64)
+    par = V.VocoderParams(16, 3, np.ones(10), lib=gpu_lib)     # W = 10, H = 3
+    frames, left = Cd.frames_of_e(par, data)
+    assert np.array_equal(frames, g["frames_w10_h3"].astype(np.float64))
+    assert np.array_equal(left, data[frames.shape[0] * 3:])
+    assert np.array_equal(Cd.sum_frames_e(par, frames, 4), g["ola_c4_h3"].astype(np.float64).ravel())
+    assert np.array_equal(Cd.sum_frames_e(par, frames, 16), g["ola_c16_h3"].astype(np.float64).ravel())
+    par.close()
+
+
+def test_empty_and_degenerate_inputs(gpu_lib, orc):
+    from vocoder_amd import vocoder as V, conduit as Cd
+    win = orc.make_window("hann", 64)
+    par = V.VocoderParams(64, 16, win, lib=gpu_lib)
+    ph = np.arange(33.0)
+    p2, (mag, inc) = V.analysis_stage(par, ph, np.empty((0, 64)))       # mapAccumL over no frames
+    assert np.array_equal(p2, ph) and mag.shape == (0, 33)
+    y, left, (a, s) = Cd.process_with(par, np.empty(0))
+    assert y.size == 0 and left.size == 0
+    y, left, _ = Cd.process_with(par, np.ones(63))
+    assert y.size == 0 and np.array_equal(left, np.ones(63))
+    with pytest.raises(V.VocoderError):
+        V.VocoderParams(64, 16, np.ones(65), lib=gpu_lib)               # addZeroPadding error (Vocoder.hs:132)
+    with pytest.raises(V.VocoderError):
+        V.do_fft(par, np.ones(60))                                      # size mismatch
+    par.close()
+
+
+def test_streaming_state_equals_one_shot(gpu_lib, orc):
+    """Feeding a stream in pieces through (leftover, phases) gives the one-shot result: the carry
+    triple is the reference's own resume state (Conduit.hs:46-53, Audio.hs:31-33)."""
+    from vocoder_amd import vocoder as V, conduit as Cd
+    rng = np.random.default_rng(9)
+    n, h = 512, 128
+    win = orc.make_window("hann", n)
+    par = V.VocoderParams(n, h, win, lib=gpu_lib)
+    x = rng.standard_normal((2, 20000))
+    y_all, left_all, (a_all, s_all) = Cd.process_with(par, x)
+    left, phases, pieces = None, None, []
+    for lo, hi in ((0, 3000), (3000, 3100), (3100, 11111), (11111, 20000)):
+        y, left, phases = Cd.process_with(par, x[:, lo:hi], leftover=left, phases=phases)
+        pieces.append(y)
+    # each call's overlap-add output restarts at its own first frame: overlap the pieces at hop multiples
+    total = np.zeros_like(y_all)
+    pos = 0
+    for lo, piece in zip((0, 3000, 3100, 11111), pieces):
+        total[:, pos:pos + piece.shape[1]] += piece[:, : total.shape[1] - pos]
+        nf = piece.shape[1] // h - (n // h - 1) if piece.shape[1] else 0
+        pos += max(nf, 0) * h
+    assert Hh.rel_l2(total, y_all) <= Hh.TOL_L2
+    assert np.array_equal(left, left_all)
+    assert Hh.circ_dist(phases[0], a_all).max() <= Hh.TOL_PHASE
+    par.close()
+
+
+def test_device_entry_matches_host_entry_and_runs_the_native_library(gpu_lib, orc):
+    import torch
+    from vocoder_amd import vocoder as V, conduit as Cd
+    rng = np.random.default_rng(4)
+    n, h, c, length = 4096, 1024, 5, 70000
+    win = orc.make_window("hann", n)
+    par = V.VocoderParams(n, h, win, lib=gpu_lib)
+    x = Hh.signal(rng, c, length, "tone")
+    y_host, left_host, (a_host, s_host) = Cd.process_with(par, x)
+    dev = torch.device("cuda:0")
+    xd = torch.from_numpy(x).to(dev)
+    f = Cd.num_frames(par, length)
+    yd = torch.full((c, Cd.ola_length(par, f, h) + 3), 7.0, dtype=torch.float64, device=dev)   # padded rows
+    ad = torch.zeros(c, par.K, dtype=torch.float64, device=dev)
+    sd = torch.zeros_like(ad)
+    ld = torch.empty(c, Cd.leftover_length(par, length), dtype=torch.float64, device=dev)
+    ws = torch.empty(Cd.roundtrip_workspace_bytes(par, length, c), dtype=torch.uint8, device=dev)
+    Cd.process_dev(par, xd, yd, ad, sd, leftover=ld, workspace=ws)
+    torch.cuda.synchronize()
+    assert np.array_equal(yd[:, :-3].cpu().numpy(), y_host)        # same kernels, same bits
+    assert torch.all(yd[:, -3:] == 7.0)                            # bytes between rows untouched
+    assert np.array_equal(ld.cpu().numpy(), left_host)
+    assert np.array_equal(ad.cpu().numpy(), a_host) and np.array_equal(sd.cpu().numpy(), s_host)
+    # small workspace: the library walks the channels in groups and gets the same answer
+    small = torch.empty(Cd.roundtrip_workspace_bytes(par, length, 2), dtype=torch.uint8, device=dev)
+    yd2 = torch.zeros_like(yd)
+    ad.zero_(); sd.zero_()
+    Cd.process_dev(par, xd, yd2, ad, sd, workspace=small)
+    torch.cuda.synchronize()
+    assert np.array_equal(yd2[:, :-3].cpu().numpy(), y_host)
+    par.close()
+    loaded = open("/proc/self/maps").read()
+    assert "libvocoder_hip.so" in loaded and "libvocoder_emu" not in loaded and "libvocoder_oracle" in loaded

@@ -1,0 +1,66 @@
+"""Kernel index logic on the CPU: the kernel SOURCE (vocoder_amd/csrc/voc_kernels.h and the C-ABI
+layer) compiled for the host through tools/emu/hip_emu.h -- one std::thread per HIP thread, real
+barriers -- and checked against the oracle.  This is a development harness for machines without
+a GPU; it is not a code path of the product (which fails when libvocoder_hip.so is missing) and
+claims nothing about the GPU build's numerics.  The parity tests proper are in test_gpu_*.py."""
+import numpy as np
+import pytest
+
+import helpers as Hh
+
+
+@pytest.mark.parametrize("n,w,h", [(8, 8, 2), (16, 16, 4), (64, 48, 16), (128, 100, 30), (512, 512, 128)])
+def test_fft_layer(emu_lib, orc, n, w, h):
+    Hh.check_fft_layer(emu_lib, orc, n, w, h, np.random.default_rng(n))
+
+
+@pytest.mark.parametrize("n,w,h,f,c,at,st", [
+    (64, 64, 16, 9, 2, 0, 0),      # one tile per channel
+    (64, 48, 16, 23, 2, 4, 5),     # zero-padded frames, several tiles with carries
+    (128, 100, 30, 17, 1, 3, 7),   # hop that does not divide the window
+    (64, 64, 64, 7, 1, 2, 3),      # no overlap
+])
+def test_stages(emu_lib, orc, n, w, h, f, c, at, st):
+    Hh.check_stages(emu_lib, orc, n, w, h, f, c, np.random.default_rng(1), ana_tile=at, syn_tile=st)
+
+
+@pytest.mark.parametrize("n,w,h,length,c,at,st,chunk", [
+    (64, 64, 16, 64 + 16 * 12 + 5, 2, 0, 0, None),
+    (64, 48, 16, 48 + 16 * 22 + 3, 2, 4, 5, 48),   # tiles with halo recompute, chunk != hop
+    (64, 32, 40, 32 + 40 * 8, 1, 2, 4, None),      # hop larger than the window: gaps of zeros
+    (128, 128, 32, 100, 2, 0, 0, None),            # shorter than one frame: no output, all leftover
+    (128, 128, 32, 128, 1, 0, 0, 50),              # exactly one frame
+])
+def test_roundtrip(emu_lib, orc, n, w, h, length, c, at, st, chunk):
+    Hh.check_roundtrip(emu_lib, orc, n, w, h, length, c, np.random.default_rng(2), ana_tile=at, syn_tile=st, chunk=chunk)
+
+
+def test_steps_and_framing(emu_lib, orc):
+    from vocoder_amd import vocoder as V, conduit as Cd
+    rng = np.random.default_rng(3)
+    n, w, h = 64, 48, 12
+    win = orc.make_window("hamming", w)
+    par = V.VocoderParams(n, h, win, lib=emu_lib)
+    k = par.K
+    spec = rng.standard_normal((4, k)) + 1j * rng.standard_normal((4, k))
+    prev = rng.uniform(-3, 3, (4, k))
+    ph, (mag, inc) = V.analysis_step(par, prev, spec)
+    for b in range(4):
+        rp, rm, ri = orc.analysis_step(h, n, prev[b], spec[b])
+        assert np.abs(mag[b] - rm).max() <= 1e-15 * rm.max()
+        assert Hh.circ_dist(ph[b], rp).max() <= 1e-14 and Hh.circ_dist(inc[b] * h, ri * h).max() <= 1e-12
+    nph, sp = V.synthesis_step(par, prev, (mag, inc))
+    for b in range(4):
+        rp, rs = orc.synthesis_step(h, prev[b], mag[b], inc[b])
+        assert np.array_equal(nph[b], rp) and np.abs(sp[b] - rs).max() <= 1e-14 * np.abs(rs).max()
+    x = rng.standard_normal((2, 333))
+    frames, left = Cd.frames_of_e(par, x)
+    for ch in range(2):
+        rf, rl = orc.gen_frames_of_e(w, h, [x[ch]])
+        assert np.array_equal(frames[ch], rf) and np.array_equal(left[ch], rl)
+    for chunk in (h, 7, 100):
+        y = Cd.sum_frames_e(par, frames, chunk)
+        for ch in range(2):
+            assert np.array_equal(y[ch], orc.sum_frames_e(chunk, h, list(frames[ch])).ravel())
+    assert par.lib.dll.voc_volume_coeff(par.handle) == orc.volume_coeff(h, win)
+    par.close()

@@ -45,6 +45,8 @@ SIGNATURES = {
     "voc_sum_frames": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i64]),
     "voc_roundtrip": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64]),
     "voc_roundtrip_workspace_bytes": (_i64, [_vp, _i64, _i64]),
+    "voc_profile_enable": (_i32, [_vp, _i32]),
+    "voc_profile_read": (_i32, [_vp, _vp, _vp]),
     "voc_roundtrip_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
 }
 

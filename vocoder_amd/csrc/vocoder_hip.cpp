@@ -29,6 +29,11 @@ struct voc_ctx {
     void *ws = nullptr;
     size_t ws_bytes = 0;
     int ana_tile_override = 0, syn_tile_override = 0;
+#ifndef VOC_EMU
+    bool profiling = false;
+    struct Timed { int kind; hipEvent_t start, stop; };
+    std::vector<Timed> timed;  // one pair of events per kernel launch while profiling
+#endif
     std::mutex mu;
     std::string hip_err;
 };
@@ -71,6 +76,29 @@ struct DevBuf {  // device allocation owned for the duration of one host-pointer
     double *d() const { return static_cast<double *>(p); }
 };
 
+enum { KIND_ANALYSIS = 0, KIND_CARRY = 1, KIND_SYNTHESIS = 2, KIND_OTHER = 3, KIND_COUNT = 4 };
+
+// While profiling is on, brackets one kernel launch with HIP events on the launch stream.
+struct LaunchTimer {
+#ifndef VOC_EMU
+    voc_ctx *c;
+    hipStream_t st;
+    hipEvent_t stop = nullptr;
+    LaunchTimer(voc_ctx *c_, int kind, hipStream_t st_) : c(c_), st(st_)
+    {
+        if (!c->profiling) return;
+        hipEvent_t start;
+        HIPCHK(hipEventCreate(&start));
+        HIPCHK(hipEventCreate(&stop));
+        HIPCHK(hipEventRecord(start, st));
+        c->timed.push_back({kind, start, stop});
+    }
+    ~LaunchTimer() { if (stop) (void)hipEventRecord(stop, st); }
+#else
+    LaunchTimer(voc_ctx *, int, hipStream_t) {}
+#endif
+};
+
 inline long long floordiv(long long a, long long b)
 {
     long long q = a / b;
@@ -91,12 +119,6 @@ inline size_t lds_bytes(const voc_ctx *c, bool ola)
     return b;
 }
 
-inline int threads_for(const voc_ctx *c)
-{
-    int t = c->M / 8;
-    return t < 64 ? 64 : (t > 1024 ? 1024 : t);
-}
-
 #define VOC_FOR_EACH_LOG2M(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
 
 template <bool RAW, bool SPEC>
@@ -105,6 +127,7 @@ void launch_analysis(voc_ctx *c, const voc::AnaArgs &a, long long channels, hipS
     const long long grid = channels * a.tiles;
     if (grid <= 0) return;
     if (grid > 0x7fffffffLL) throw HipFail{hipErrorInvalidValue, "analysis grid too large"};
+    LaunchTimer timer(c, SPEC ? KIND_OTHER : KIND_ANALYSIS, st);
     switch (c->log2m) {
 #define X(L)                                                                                              \
     case L:                                                                                               \
@@ -123,6 +146,7 @@ void launch_synthesis(voc_ctx *c, const voc::SynArgs &a, long long channels, hip
     const long long grid = channels * a.tiles;
     if (grid <= 0) return;
     if (grid > 0x7fffffffLL) throw HipFail{hipErrorInvalidValue, "synthesis grid too large"};
+    LaunchTimer timer(c, IN_MODE == voc::SYN_IN_SPEC ? KIND_OTHER : KIND_SYNTHESIS, st);
     switch (c->log2m) {
 #define X(L)                                                                                                    \
     case L:                                                                                                     \
@@ -250,6 +274,7 @@ void synthesis_stage_dev(voc_ctx *c, double *phase_io, const double *mag, const 
     HIPCHK(hipMemcpyAsync(pin, phase_io, pin_bytes, hipMemcpyDeviceToDevice, st));
     if (tiles > 1) {
         const long long chains = C * c->K;
+        LaunchTimer timer(c, KIND_CARRY, st);
         hipLaunchKernelGGL(voc::phase_carry_kernel, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st,
                            c->params, inc, (long long)c->K, F, pin, carry, tile_len, tiles, 0, C);
         HIPCHK(hipGetLastError());
@@ -272,8 +297,11 @@ void synthesis_stage_dev(voc_ctx *c, double *phase_io, const double *mag, const 
 struct RtPlan {
     long long F, out_len, ldk;
     int ana_tile, ana_tiles, syn_tile, syn_tiles, halo;
-    size_t per_channel_bytes;  // STFT + carry + two phase snapshots
+    bool fused_ola;            // overlap-add ring fits in LDS beside the FFT buffer
+    size_t per_channel_bytes;  // STFT + carry + two phase snapshots (+ frames when not fused)
 };
+
+constexpr size_t kLdsLimit = 160 * 1024;
 
 RtPlan roundtrip_plan(const voc_ctx *c, long long len, long long group, long long chunk)
 {
@@ -281,13 +309,15 @@ RtPlan roundtrip_plan(const voc_ctx *c, long long len, long long group, long lon
     r.F = num_frames(c, len);
     r.out_len = ola_length(c, r.F, chunk > 0 ? chunk : c->H);
     r.ldk = (c->K + 1) & ~1LL;
-    r.halo = (c->W + c->H - 1) / c->H - 1;
+    r.fused_ola = lds_bytes(c, true) <= kLdsLimit;
+    r.halo = r.fused_ola ? (c->W + c->H - 1) / c->H - 1 : 0;
     if (r.F > 0) {
         r.ana_tile = analysis_tile_len(c, group, r.F);
         r.ana_tiles = (int)((r.F + r.ana_tile - 1) / r.ana_tile);
         synthesis_tiling(c, group, r.F, r.halo, &r.syn_tile, &r.syn_tiles);
     }
-    r.per_channel_bytes = (size_t)(2 * r.F * r.ldk + (long long)(r.syn_tiles > 1 ? r.syn_tiles : 0) * c->K + 2LL * c->K) *
+    r.per_channel_bytes = (size_t)(2 * r.F * r.ldk + (long long)(r.syn_tiles > 1 ? r.syn_tiles : 0) * c->K + 2LL * c->K +
+                                   (r.fused_ola ? 0 : r.F * c->W)) *
                           sizeof(double);
     return r;
 }
@@ -332,6 +362,7 @@ void roundtrip_dev(voc_ctx *c, const double *x, long long x_stride, long long le
         double *pinA = inc + (size_t)G * F * r.ldk;
         double *pinS = pinA + (size_t)G * c->K;
         double *carry = pinS + (size_t)G * c->K;
+        double *frames = carry + (size_t)(r.syn_tiles > 1 ? r.syn_tiles : 0) * G * c->K;  // only when !fused_ola
         double *aph = ana_phase + c0 * c->K, *sph = syn_phase + c0 * c->K;
         HIPCHK(hipMemcpyAsync(pinA, aph, (size_t)G * c->K * sizeof(double), hipMemcpyDeviceToDevice, st));
         HIPCHK(hipMemcpyAsync(pinS, sph, (size_t)G * c->K * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -353,6 +384,7 @@ void roundtrip_dev(voc_ctx *c, const double *x, long long x_stride, long long le
 
         if (r.syn_tiles > 1) {
             const long long chains = G * c->K;
+            LaunchTimer timer(c, KIND_CARRY, st);
             hipLaunchKernelGGL(voc::phase_carry_kernel, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st,
                                c->params, inc, r.ldk, F, pinS, carry, r.syn_tile, r.syn_tiles, r.halo, G);
             HIPCHK(hipGetLastError());
@@ -371,7 +403,17 @@ void roundtrip_dev(voc_ctx *c, const double *x, long long x_stride, long long le
         s.tile_len = r.syn_tile;
         s.tiles = r.syn_tiles;
         s.halo = r.halo;
-        launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_OLA>(c, s, G, st);
+        if (r.fused_ola) {
+            launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_OLA>(c, s, G, st);
+        } else {
+            // frame too long for an LDS-resident overlap-add ring: frames go through HBM once
+            s.out = frames;
+            launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_FRAMES>(c, s, G, st);
+            const long long total = G * r.out_len;
+            hipLaunchKernelGGL(voc::sum_frames_kernel, dim3(ew_grid(total)), dim3(256), 0, st, frames, F, c->W, c->H,
+                               y + c0 * y_stride, (long long)y_stride, r.out_len, total);
+            HIPCHK(hipGetLastError());
+        }
     }
 }
 
@@ -793,4 +835,42 @@ VOC_EXPORT int32_t voc_roundtrip(voc_ctx *c, const double *x, int64_t x_stride, 
         HIPCHK(hipMemcpy(syn_phase_io, ds.p, nph, hipMemcpyDeviceToHost));
         return VOC_OK;
     });
+}
+
+// ---- measurement hook -----------------------------------------------------------------------------------------
+
+VOC_EXPORT int32_t voc_profile_enable(voc_ctx *c, int32_t on)
+{
+    if (!c) return VOC_ERR_INVALID;
+#ifndef VOC_EMU
+    std::lock_guard<std::mutex> g(c->mu);
+    c->profiling = on != 0;
+#else
+    (void)on;
+#endif
+    return VOC_OK;
+}
+
+VOC_EXPORT int32_t voc_profile_read(voc_ctx *c, double *ms, int64_t *launches)
+{
+    if (!c || !ms || !launches) return VOC_ERR_INVALID;
+    for (int k = 0; k < KIND_COUNT; ++k) { ms[k] = 0.0; launches[k] = 0; }
+#ifndef VOC_EMU
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c);
+        for (auto &t : c->timed) {
+            float e = 0.f;
+            HIPCHK(hipEventSynchronize(t.stop));
+            HIPCHK(hipEventElapsedTime(&e, t.start, t.stop));
+            ms[t.kind] += e;
+            launches[t.kind] += 1;
+            (void)hipEventDestroy(t.start);
+            (void)hipEventDestroy(t.stop);
+        }
+        c->timed.clear();
+        return VOC_OK;
+    });
+#else
+    return VOC_OK;
+#endif
 }
