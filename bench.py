@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=1024, help="streams per GPU (metric configuration: 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-streams", type=int, default=6, help="streams of the workload the CPU oracle is timed on")
+    ap.add_argument("--cpu-streams", type=int, default=24, help="streams of the workload the CPU oracle is timed on")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

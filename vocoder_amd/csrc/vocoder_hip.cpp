@@ -188,7 +188,7 @@ void synthesis_tiling(const voc_ctx *c, long long channels, long long F, int hal
     if (c->syn_tile_override > 0) {
         tl = c->syn_tile_override;
     } else {
-        long long want = (2048 + channels - 1) / channels;  // tiles per channel to reach ~2048 workgroups
+        long long want = (1024 + channels - 1) / channels;  // tiles per channel to reach ~1024 workgroups
         long long min_tile = 8LL * (halo + 1);
         if (min_tile < 16) min_tile = 16;
         long long max_tiles = F / min_tile;
