@@ -40,7 +40,7 @@ struct Params {
     int hop_pow2;  // H is a power of two: x / H == x * (1/H) exactly
     double hop_d, inv_hop, inv_n;
     const double *window;  // [W]
-    const double2 *twM;    // [M]      exp(-2 pi i m / M)
+    const double2 *twP;    // [M-1]    per-pass twiddles, see fft_passes
     const double2 *twS;    // [M/2+1]  exp(-2 pi i k / N)
 };
 
@@ -126,25 +126,36 @@ VOC_DEV void dft<8>(double2 (&v)[8])
 // in[i + j*M/RAD], multiplies by exp(-2 pi i j k / (NS*RAD)) with k = i mod NS, and
 // writes out[(i-k)*RAD + k + j*NS].  Reads come through `ld` (LDS or a fused global
 // loader for the first pass); writes go to LDS in place, fenced by two barriers.
+//
+// Twiddles: twP holds, pass after pass, the factors of every pass with NS > 1 as
+// [j-1][k] (k fastest), the pass at stride NS starting at entry NS - 1 -- so for a fixed j
+// consecutive lanes read consecutive 16-byte entries, and the seven loads of a butterfly
+// share one per-lane offset.
+// LDS: element e lives at e + e/8 (one 16-byte pad per 8 elements keeps the stride-8 stores
+// of the first pass off a single bank); when a stride is a multiple of 8 the padded index
+// is linear in j, which the code spells out so that the j-th access is base + constant.
 template <int M, int T, int NS, class Loader>
-VOC_DEV void fft_passes(double2 *lds, const double2 *__restrict__ twM, int tid, Loader ld)
+VOC_DEV void fft_passes(double2 *lds, const double2 *__restrict__ twP, int tid, Loader ld)
 {
     constexpr int REM = M / NS;
     constexpr int RAD = REM >= 8 ? 8 : REM;
     constexpr int NBF = M / RAD;
     constexpr int NB = (NBF + T - 1) / T;
-    constexpr int TWS = M / (NS * RAD);
+    constexpr bool LIN_ST = (NS % 8 == 0) || (NS == 1 && RAD == 8);
     double2 v[NB][RAD];
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
         const int i = tid + q * T;
         if ((NBF % T == 0) || i < NBF) {
 #pragma unroll
-            for (int j = 0; j < RAD; ++j) v[q][j] = ld(i + j * NBF);
+            for (int j = 0; j < RAD; ++j) v[q][j] = ld(i, j);
             if (NS > 1) {
-                const int k = i & (NS - 1);
+                const unsigned k = (unsigned)i & (unsigned)(NS - 1);
 #pragma unroll
-                for (int j = 1; j < RAD; ++j) v[q][j] = cmul(v[q][j], twM[j * k * TWS]);
+                for (int j = 1; j < RAD; ++j) {
+                    const double2 *tj = twP + (NS - 1) + (j - 1) * NS;  // uniform base of row j
+                    v[q][j] = cmul(v[q][j], tj[k]);
+                }
             }
             dft<RAD>(v[q]);
         }
@@ -156,33 +167,174 @@ VOC_DEV void fft_passes(double2 *lds, const double2 *__restrict__ twM, int tid, 
         if ((NBF % T == 0) || i < NBF) {
             const int k = i & (NS - 1);
             const int j0 = (i - k) * RAD + k;
+            if (LIN_ST) {
+                double2 *dst = lds + lds_pad(j0);
 #pragma unroll
-            for (int j = 0; j < RAD; ++j) lds[lds_pad(j0 + j * NS)] = v[q][j];
+                for (int j = 0; j < RAD; ++j) dst[j * (NS + NS / 8)] = v[q][j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < RAD; ++j) lds[lds_pad(j0 + j * NS)] = v[q][j];
+            }
         }
     }
     __syncthreads();
     if constexpr (NS * RAD < M) {
-        fft_passes<M, T, NS * RAD>(lds, twM, tid, [lds](int m) { return lds[lds_pad(m)]; });
+        constexpr int NBF2 = M / ((M / (NS * RAD)) >= 8 ? 8 : (M / (NS * RAD)));
+        fft_passes<M, T, NS * RAD>(lds, twP, tid, [lds](int i, int j) {
+            if (NBF2 % 8 == 0) return (lds + lds_pad(i))[j * (NBF2 + NBF2 / 8)];
+            return lds[lds_pad(i + j * NBF2)];
+        });
     }
 }
 
-// ------------------------------------------------------------------ per-bin arithmetic
+// first-pass loader over LDS: element i + j*NBF of the M-point array
+template <int M>
+struct LdsLoader {
+    const double2 *lds;
+    static constexpr int RAD0 = M >= 8 ? 8 : M;
+    static constexpr int NBF = M / RAD0;
+    VOC_DEV double2 operator()(int i, int j) const
+    {
+        if (NBF % 8 == 0) return (lds + lds_pad(i))[j * (NBF + NBF / 8)];
+        return lds[lds_pad(i + j * NBF)];
+    }
+};
 
-// Data.Complex.magnitude: scaleFloat k (sqrt (sqr (scaleFloat (-k) x) + sqr (scaleFloat (-k) y))),
-// k = max (exponent x) (exponent y), exponent 0 = 0.
-VOC_DEV double hs_magnitude(double x, double y)
+// ------------------------------------------------------------------ per-bin arithmetic
+//
+// The transcendental functions are written out here instead of calling the device math library:
+// the path spends most of its instructions in them, and each is needed only on a restricted
+// domain.  All are accurate to about one ulp (checked against 60-digit arithmetic by
+// tools/gen_poly.py and the parity tests); inputs outside the fast domain (huge, tiny, inf, nan)
+// take the library routine.
+
+VOC_DEV double approx_rcp(double b)
 {
-    int ex = 0, ey = 0;
-    if (x != 0.0) (void)frexp(x, &ex);
-    if (y != 0.0) (void)frexp(y, &ey);
-    const int k = ex > ey ? ex : ey;
-    const double sx = ldexp(x, -k), sy = ldexp(y, -k);
-    const double a = sx * sx, b = sy * sy;
-    return ldexp(sqrt(a + b), k);
+#ifdef VOC_EMU
+    return 1.0 / b;
+#else
+    return __builtin_amdgcn_rcp(b);
+#endif
 }
 
-// Data.Complex.phase: 0 for 0:+0, else atan2 y x (range (-pi, pi], atan2(+0, x<0) = pi).
-VOC_DEV double hs_phase(double x, double y) { return (x == 0.0 && y == 0.0) ? 0.0 : atan2(y, x); }
+// a / b for b in [2^-4, 2^4], |a| <= b: hardware reciprocal seed, two Newton steps, one residual
+// correction of the quotient.
+VOC_DEV double div_pos(double a, double b)
+{
+    double r = approx_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+
+VOC_DEV int frexp_exponent(double v)  // exponent e with |v| = m 2^e, 0.5 <= m < 1; 0 for v = 0
+{
+#ifdef VOC_EMU
+    int e = 0;
+    if (v != 0.0) (void)frexp(v, &e);
+    return e;
+#else
+    return __builtin_amdgcn_frexp_exp(v);
+#endif
+}
+
+// atan(t) = t + t z P(z), z = t^2, for |t| <= tan(pi/8): degree-10 minimax P (tools/gen_poly.py),
+// relative error 5e-18 before rounding.
+VOC_DEV double atan_poly(double t)
+{
+    const double z = t * t;
+    double p = -0x1.3b08efe0aa3adp-6;
+    p = fma(p, z, 0x1.41bf291d28cbdp-5);
+    p = fma(p, z, -0x1.a0bb5679f2cabp-5);
+    p = fma(p, z, 0x1.dfed1a54859f0p-5);
+    p = fma(p, z, -0x1.10fae2404e73fp-4);
+    p = fma(p, z, 0x1.3b126b14c8afbp-4);
+    p = fma(p, z, -0x1.745d0b879bfcfp-4);
+    p = fma(p, z, 0x1.c71c7187c0787p-4);
+    p = fma(p, z, -0x1.249249243a720p-3);
+    p = fma(p, z, 0x1.99999999993a8p-3);
+    p = fma(p, z, -0x1.5555555555555p-2);
+    return fma(t * z, p, t);
+}
+
+// frameFromComplex for one bin (Vocoder.hs:217-218): Data.Complex.magnitude and phase of x + iy.
+//
+// Both start from the pair scaled by 2^-e, e = exponent of max(|x|, |y|), exactly as
+// `magnitude` prescribes (scaleFloat k (sqrt (sqr (scaleFloat (-k) x) + sqr (scaleFloat (-k) y)))):
+// power-of-two scaling commutes with every rounding, so the bits match the reference's whenever
+// its own intermediate squares neither overflow nor underflow.
+//
+// phase: 0 for 0:+0, else atan2 y x in (-pi, pi] with atan2(+-0, x<0) = +-pi, as GHC's and
+// IEEE's.  q = min/max of the magnitudes is folded once, atan q = pi/4 + atan((q-1)/(q+1)) for
+// q > tan(pi/8), BEFORE the one division; then the octant is undone.  Finite inputs only: an
+// infinite or NaN component gives NaN.
+VOC_DEV void hs_polar(double x, double y, double &mag, double &ph)
+{
+    const double ax = fabs(x), ay = fabs(y);
+    const int e = frexp_exponent(fmax(ax, ay));
+    const double sx = ldexp(ax, -e), sy = ldexp(ay, -e);
+    const double a = sx * sx, b = sy * sy;
+    mag = ldexp(sqrt(a + b), e);
+    const double mx = fmax(sx, sy), mn = fmin(sx, sy);
+    const bool fold = mn > 0.41421356237309503 * mx;
+    const double num = fold ? mn - mx : mn;
+    const double den = fold ? mn + mx : mx;
+    double t = atan_poly(div_pos(num, den));
+    t = fold ? t + 0.78539816339744828 : t;
+    t = (ay > ax) ? 1.5707963267948966 - t : t;
+    t = __builtin_signbit(x) ? kPi - t : t;
+    ph = (ax == 0.0 && ay == 0.0) ? 0.0 : copysign(t, y);
+}
+
+VOC_DEV double hs_magnitude(double x, double y)
+{
+    double m, p;
+    hs_polar(x, y, m, p);
+    return m;
+}
+
+VOC_DEV double hs_phase(double x, double y)
+{
+    double m, p;
+    hs_polar(x, y, m, p);
+    return p;
+}
+
+// sin and cos of an UNWRAPPED phase: n = round(x 2/pi) by the 1.5*2^52 trick, two-step Cody-Waite
+// reduction with fma (x - n*hi is exact: both are multiples of 2^-52 and the difference is below
+// 1), then the classical degree-13 / degree-14 kernels on [-pi/4, pi/4].  Accurate to about an ulp
+// for |x| < 2^50 (a phase that large has a resolution of 0.25 rad; beyond it, and for inf / nan,
+// the result is NaN).
+VOC_DEV void fast_sincos(double x, double *sn, double *cs)
+{
+    x = (fabs(x) < 0x1p50) ? x : (x - x) / (x - x);
+    const double big = 0x1.8p52;
+    const double tn = fma(x, 0.63661977236758138, big);
+    const double n = tn - big;
+    const unsigned q = (unsigned)__builtin_bit_cast(unsigned long long, tn);
+    double r = fma(-n, 1.5707963267948966, x);
+    r = fma(-n, 6.123233995736766e-17, r);
+    const double z = r * r;
+    double ps = 1.58969099521155010221e-10;
+    ps = fma(ps, z, -2.50507602534068634195e-08);
+    ps = fma(ps, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    ps = fma(ps, z, 8.33333333332248946124e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);
+    const double s = fma(r * z, ps, r);
+    double pc = -1.13596475577881948265e-11;
+    pc = fma(pc, z, 2.08757232129817482790e-09);
+    pc = fma(pc, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+    pc = fma(pc, z, -1.38888888888741095749e-03);
+    pc = fma(pc, z, 4.16666666666666019037e-02);
+    const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const double s1 = (q & 1u) ? c : s;
+    const double c1 = (q & 1u) ? s : c;
+    *sn = (q & 2u) ? -s1 : s1;
+    *cs = ((q + 1u) & 2u) ? -c1 : c1;
+}
 
 // wrap e = (e + pi) `mod'` (2 pi) - pi with mod' n d = n - floor(n/d) * d and the floor taken
 // of the exact quotient (Vocoder.hs:166-167, Data.Fixed).  The exact floor is recovered from
@@ -190,9 +342,11 @@ VOC_DEV double hs_phase(double x, double y) { return (x == 0.0 && y == 0.0) ? 0.
 VOC_DEV double hs_wrap(double e)
 {
     const double n = e + kPi;
-    double f = floor(n * kInvTwoPi);
-    if (fma(-f, kTwoPi, n) < 0.0) f -= 1.0;
-    else if (fma(-(f + 1.0), kTwoPi, n) >= 0.0) f += 1.0;
+    const double f0 = floor(n * kInvTwoPi);
+    const double fm = f0 - 1.0, fp = f0 + 1.0;
+    const bool below = fma(-f0, kTwoPi, n) < 0.0;   // exact sign of n - f0*2pi
+    const bool above = fma(-fp, kTwoPi, n) >= 0.0;  // exact sign of n - (f0+1)*2pi
+    const double f = below ? fm : (above ? fp : f0);
     const double t = f * kTwoPi;
     return (n - t) - kPi;
 }
@@ -208,9 +362,10 @@ VOC_DEV double phase_inc(const Params &p, int k, double ph_diff)
 // analysisStep for one bin (Vocoder.hs:158-163).  `prev` is replaced by the new raw phase.
 VOC_DEV void analyze_bin(const Params &p, int k, double2 X, double &prev, bool emit, double vol, double *mag, double *inc)
 {
-    const double ph = hs_phase(X.x, X.y);
+    double m, ph;
+    hs_polar(X.x, X.y, m, ph);
     if (emit) {
-        *mag = hs_magnitude(X.x, X.y) * vol;
+        *mag = m * vol;
         *inc = phase_inc(p, k, ph - prev);
     }
     prev = ph;
@@ -222,7 +377,7 @@ VOC_DEV double2 synthesize_bin(const Params &p, double mag, double inc, double &
     const double t = inc * p.hop_d;
     ph = ph + t;
     double s, c;
-    sincos(ph, &s, &c);
+    fast_sincos(ph, &s, &c);
     return make_double2(mag * c, mag * s);
 }
 
@@ -245,7 +400,7 @@ struct AnaArgs {
 // RAW: plain R2C of N contiguous reals (no window / pad / rewind).  SPEC_OUT: write the complex
 // spectrum instead of (mag, ph_inc).
 template <int LOG2M, bool RAW, bool SPEC_OUT>
-__global__ void __launch_bounds__(Cfg<LOG2M>::T) analysis_kernel(Params p, AnaArgs a)
+__global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) analysis_kernel(Params p, AnaArgs a)
 {
     constexpr int M = Cfg<LOG2M>::M, T = Cfg<LOG2M>::T, NP = Cfg<LOG2M>::NP;
     VOC_SMEM(double2, lds);
@@ -276,7 +431,8 @@ __global__ void __launch_bounds__(Cfg<LOG2M>::T) analysis_kernel(Params p, AnaAr
         const double *fr = xc + f * a.frame_stride;
         const bool emit = f >= f0;
         // ---- first pass reads straight from global: window, zero pad, rewind, even/odd packing
-        auto loader = [&](int m) -> double2 {
+        auto loader = [&](int i, int j) -> double2 {
+            const int m = i + j * (M / (M >= 8 ? 8 : M));
             if (RAW) return make_double2(fr[2 * m], fr[2 * m + 1]);
             const int i0 = ((2 * m + M) & (p.N - 1)) - p.hd;       // rewind: v[n] = padded[(n + N/2) mod N]
             const int i1 = ((2 * m + 1 + M) & (p.N - 1)) - p.hd;
@@ -285,7 +441,7 @@ __global__ void __launch_bounds__(Cfg<LOG2M>::T) analysis_kernel(Params p, AnaAr
             z.y = (i1 >= 0 && i1 < p.W) ? p.window[i1] * fr[i1] : 0.0;
             return z;
         };
-        fft_passes<M, T, 1>(lds, p.twM, tid, loader);
+        fft_passes<M, T, 1>(lds, p.twP, tid, loader);
         // ---- real-FFT split + per-bin analysis.  Z[k] is at lds[pad(k)].
         const long long row = c * a.F + f;
 #pragma unroll
@@ -378,7 +534,7 @@ struct SynArgs {
 };
 
 template <int LOG2M, int IN_MODE, int OUT_MODE>
-__global__ void __launch_bounds__(Cfg<LOG2M>::T) synthesis_kernel(Params p, SynArgs a)
+__global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) synthesis_kernel(Params p, SynArgs a)
 {
     constexpr int M = Cfg<LOG2M>::M, T = Cfg<LOG2M>::T, NP = Cfg<LOG2M>::NP, NQ = Cfg<LOG2M>::NQ;
     VOC_SMEM(double2, lds);
@@ -452,7 +608,7 @@ __global__ void __launch_bounds__(Cfg<LOG2M>::T) synthesis_kernel(Params p, SynA
             lds[lds_pad(M / 2)] = make_double2(-2.0 * A.y, 2.0 * A.x);  // Z = 2 conj A, swapped
         }
         __syncthreads();
-        fft_passes<M, T, 1>(lds, p.twM, tid, [lds](int m) { return lds[lds_pad(m)]; });
+        fft_passes<M, T, 1>(lds, p.twP, tid, LdsLoader<M>{lds});
         // ---- lds[pad(m)] = swapped z[m]: v[2m] = z.y / N, v[2m+1] = z.x / N  (C2R scaled by 1/N)
         const bool emit = f >= f0;
 #pragma unroll
@@ -600,12 +756,11 @@ __global__ void add_frames_kernel(const double *mag1, const double *inc1, const 
 {
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
         double s1, c1, s2, c2;
-        sincos(inc1[g], &s1, &c1);
-        sincos(inc2[g], &s2, &c2);
+        fast_sincos(inc1[g], &s1, &c1);
+        fast_sincos(inc2[g], &s2, &c2);
         const double re = mag1[g] * c1 + mag2[g] * c2;
         const double im = mag1[g] * s1 + mag2[g] * s2;
-        mag_out[g] = hs_magnitude(re, im);
-        inc_out[g] = hs_phase(re, im);
+        hs_polar(re, im, mag_out[g], inc_out[g]);
     }
 }
 

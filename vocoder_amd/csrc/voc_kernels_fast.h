@@ -1,0 +1,497 @@
+// voc_kernels_fast.h -- the hot-path kernels for 1024 <= N <= 8192 (M = N/2 complex points,
+// T = M/8 threads per frame: 8 complex points and 4 (k, M-k) bin pairs per thread).
+//
+// Same arithmetic as the generic kernels in voc_kernels.h.  What differs is scheduling: a
+// workgroup's per-frame critical path is a chain of memory round trips (input samples, per-pass
+// twiddles, split twiddles, STFT rows) separated by barriers, and with three workgroups per CU
+// there are too few waves to hide them.  So every global load is issued one stage ahead of its
+// use, and always BEFORE the stores of the current stage (loads and stores retire in issue
+// order, so a load queued behind stores waits for them):
+//   - the next frame's samples / window (analysis) or STFT row (synthesis) are fetched while the
+//     current frame is still in its last FFT pass;
+//   - the twiddles of FFT pass p+1 are fetched before the barriers that end pass p;
+//   - the split twiddles exp(-2 pi i k / N) of a thread's four bin pairs are frame invariant and
+//     stay in registers for the life of the workgroup.
+// State carried from frame to frame (previous raw phase in analysis, accumulated phase in
+// synthesis) sits in an LDS array of K doubles that only the owning thread touches; the
+// overlap-add partial sums of the N-sample window sit in 16 registers per thread (sample i of
+// the window belongs to thread i mod T) and shift by H/T slots per frame.
+#pragma once
+
+#include "voc_kernels.h"
+
+#ifndef VOC_FAST_WAVES
+#define VOC_FAST_WAVES 3  // waves per SIMD the fast kernels are register-budgeted for
+#endif
+
+namespace voc {
+
+template <int LOG2M>
+struct FastCfg {
+    static constexpr int M = 1 << LOG2M;
+    static constexpr int T = M / 8;
+    static constexpr int K = M + 1;
+    static constexpr int R4 = M / 512;               // radix of the fourth pass (1: there is none)
+    static constexpr int NB4 = R4 > 1 ? 8 / R4 : 1;  // fourth-pass butterflies per thread
+    static constexpr int LDS_CPLX = Cfg<LOG2M>::LDS_CPLX;
+    static constexpr int LDS_BYTES = LDS_CPLX * 16 + ((K + 1) & ~1) * 8;
+};
+
+// real-FFT split of the pair (Z[pe], Z[q]), q = M - pe:  X[pe] = E + W^pe O,  X[q] = conj(E - W^pe O)
+VOC_DEV void split_pair(double2 P, double2 Q, double2 tw, double2 &Xa, double2 &Xb)
+{
+    const double2 E = make_double2(0.5 * (P.x + Q.x), 0.5 * (P.y - Q.y));
+    const double2 O = make_double2(0.5 * (P.y + Q.y), 0.5 * (Q.x - P.x));
+    const double2 U = cmul(tw, O);
+    Xa = cadd(E, U);
+    Xb = cconj(csub(E, U));
+}
+
+// inverse of split_pair, without the factor 1/2 (folded into the final 1/N):
+// Z[pe] = S + i Tw, Z[q] = conj S + i conj Tw with S = A + conj B, Tw = W^-pe (A - conj B);
+// both are returned with re and im swapped (the forward FFT then performs the backward transform).
+VOC_DEV void merge_pair(double2 A, double2 B, double2 tw, double2 &Za, double2 &Zb)
+{
+    const double2 S = make_double2(A.x + B.x, A.y - B.y);
+    const double2 D = make_double2(A.x - B.x, A.y + B.y);
+    const double2 Tw = cmul_conj(D, tw);
+    Za = make_double2(S.y + Tw.x, S.x - Tw.y);
+    Zb = make_double2(Tw.x - S.y, S.x + Tw.y);
+}
+
+// ---- the four Stockham passes, split into load / compute / store so that callers can place
+//      prefetches between them.  Index algebra as in fft_passes (voc_kernels.h).
+//
+// Twiddles are not loaded per frame.  In the pass at stride NS thread tid needs
+// exp(-2 pi i j k / (8 NS)), j = 1..7, for the one k = tid mod NS it owns in every frame: it keeps
+// the j = 1 factor in registers for the life of the workgroup and forms the powers by
+// multiplication (each power is at most three complex multiplications from the table value).
+
+// Marks a register-resident value as changed without emitting an instruction.  Everything derived
+// from the frame-invariant twiddle bases below is loop invariant, and the compiler would otherwise
+// hoist all of it (84 registers of twiddle powers) out of the frame loop and spill it.
+VOC_DEV void opaque(double2 &a)
+{
+#ifndef VOC_EMU
+    asm volatile("" : "+v"(a.x), "+v"(a.y));
+#else
+    (void)a;
+#endif
+}
+
+// Same for an integer: index arithmetic derived from an opaque copy of the thread id is redone
+// every frame (a few integer instructions) instead of being hoisted as dozens of loop-invariant
+// address registers.
+VOC_DEV int opaque_int(int v)
+{
+#ifndef VOC_EMU
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+
+VOC_DEV void sched_fence()
+{
+#ifndef VOC_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+VOC_DEV double2 csqr(double2 a) { return make_double2(fma(a.x, a.x, -(a.y * a.y)), (a.x + a.x) * a.y); }
+
+template <int LOG2M>
+struct FastTw {
+    double2 b, c;                           // base factors of the passes at stride 8 and 64
+    double2 d[FastCfg<LOG2M>::NB4];         // base factors of the fourth pass (stride 512), one per butterfly
+    double2 s;                              // exp(-2 pi i tid / N): base of the split twiddles
+};
+
+template <int LOG2M>
+VOC_DEV void fast_tw_init(const Params &p, int tid, FastTw<LOG2M> &t)
+{
+    constexpr int T = FastCfg<LOG2M>::T, R4 = FastCfg<LOG2M>::R4;
+    t.b = p.twP[7 + (tid & 7)];
+    t.c = p.twP[63 + (tid & 63)];
+#pragma unroll
+    for (int q = 0; q < FastCfg<LOG2M>::NB4; ++q) t.d[q] = R4 > 1 ? p.twP[511 + ((tid + q * T) & 511)] : make_double2(1.0, 0.0);
+    t.s = p.twS[tid];
+}
+
+// split twiddle of bin pair slot m of this thread: exp(-2 pi i (tid + m T) / N) = s * exp(-2 pi i m / 16);
+// thread 0's slot 0 holds the self-paired bin M/2 instead, whose factor is exp(-i pi/2) = -i exactly.
+VOC_DEV double2 split_tw(double2 s, int m, bool self_pair)
+{
+    opaque(s);
+    const double cr = m == 0 ? 1.0 : (m == 1 ? 0.92387953251128673848 : (m == 2 ? 0.70710678118654752440 : 0.38268343236508977173));
+    const double ci = m == 0 ? 0.0 : (m == 1 ? -0.38268343236508977173 : (m == 2 ? -0.70710678118654752440 : -0.92387953251128673848));
+    const double2 w = cmul(s, make_double2(cr, ci));
+    return self_pair ? make_double2(0.0, -1.0) : (m == 0 ? s : w);
+}
+
+template <int LOG2M>
+VOC_DEV void load8(const double2 *lds, int tid, double2 (&v)[8])
+{
+    constexpr int T = FastCfg<LOG2M>::T;
+    const double2 *src = lds + lds_pad(tid);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[j * (T + T / 8)];
+}
+
+template <int LOG2M, int NS>  // store of a radix-8 pass at stride NS (1, 8 or 64)
+VOC_DEV void store8(double2 *lds, int tid, const double2 (&v)[8])
+{
+    const int k = tid & (NS - 1);
+    double2 *dst = lds + lds_pad((tid - k) * 8 + k);
+    constexpr int STEP = NS == 1 ? 1 : NS + NS / 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dst[j * STEP] = v[j];
+}
+
+// v[j] *= w^j, j = 1..7
+VOC_DEV void twiddle8(double2 (&v)[8], double2 w1)
+{
+    opaque(w1);
+    const double2 w2 = csqr(w1);
+    v[1] = cmul(v[1], w1);
+    v[2] = cmul(v[2], w2);
+    const double2 w3 = cmul(w2, w1);
+    v[3] = cmul(v[3], w3);
+    const double2 w4 = csqr(w2);
+    v[4] = cmul(v[4], w4);
+    v[5] = cmul(v[5], cmul(w4, w1));
+    v[6] = cmul(v[6], csqr(w3));
+    v[7] = cmul(v[7], cmul(w4, w3));
+}
+
+// fourth pass: load, twiddle, butterfly (results stay in v); pass4_store writes them
+template <int LOG2M>
+VOC_DEV void pass4_compute(const double2 *lds, int tid, const FastTw<LOG2M> &t, double2 (&v)[8])
+{
+    constexpr int R4 = FastCfg<LOG2M>::R4, T = FastCfg<LOG2M>::T, M = FastCfg<LOG2M>::M;
+    if constexpr (R4 > 1) {
+        constexpr int NBF = M / R4;
+#pragma unroll
+        for (int q = 0; q < FastCfg<LOG2M>::NB4; ++q) {
+            const double2 *src = lds + lds_pad(tid + q * T);
+            double2 w[R4];
+#pragma unroll
+            for (int j = 0; j < R4; ++j) w[j] = src[j * (NBF + NBF / 8)];
+            double2 pw = t.d[q];
+            opaque(pw);
+            w[1] = cmul(w[1], pw);
+            if constexpr (R4 >= 4) {
+                const double2 w2 = csqr(pw);
+                w[2] = cmul(w[2], w2);
+                const double2 w3 = cmul(w2, pw);
+                w[3] = cmul(w[3], w3);
+                if constexpr (R4 == 8) {
+                    const double2 w4 = csqr(w2);
+                    w[4] = cmul(w[4], w4);
+                    w[5] = cmul(w[5], cmul(w4, pw));
+                    w[6] = cmul(w[6], csqr(w3));
+                    w[7] = cmul(w[7], cmul(w4, w3));
+                }
+            }
+            dft<R4>(w);
+#pragma unroll
+            for (int j = 0; j < R4; ++j) v[q * R4 + j] = w[j];
+        }
+    }
+}
+
+template <int LOG2M>
+VOC_DEV void pass4_store(double2 *lds, int tid, const double2 (&v)[8])
+{
+    constexpr int R4 = FastCfg<LOG2M>::R4, T = FastCfg<LOG2M>::T;
+    if constexpr (R4 > 1) {
+#pragma unroll
+        for (int q = 0; q < FastCfg<LOG2M>::NB4; ++q) {
+            const int i = tid + q * T;
+            const int k = i & 511;
+            double2 *dst = lds + lds_pad((i - k) * R4 + k);
+#pragma unroll
+            for (int j = 0; j < R4; ++j) dst[j * 576] = v[q * R4 + j];
+        }
+    }
+}
+
+// Passes 2..4 of the transform whose first-pass butterflies are already in v.  `prefetch` is
+// called once, after the last butterfly and before the last store: the place for the caller's
+// next-frame loads.
+template <int LOG2M, class Prefetch>
+VOC_DEV void fft_after_first(double2 *lds, const FastTw<LOG2M> &t, int tid, double2 (&v)[8], Prefetch prefetch)
+{
+    constexpr int R4 = FastCfg<LOG2M>::R4;
+    __syncthreads();
+    store8<LOG2M, 1>(lds, tid, v);
+    __syncthreads();
+    load8<LOG2M>(lds, tid, v);
+    twiddle8(v, t.b);
+    dft<8>(v);
+    __syncthreads();
+    store8<LOG2M, 8>(lds, tid, v);
+    __syncthreads();
+    load8<LOG2M>(lds, tid, v);
+    twiddle8(v, t.c);
+    dft<8>(v);
+    if (R4 == 1) prefetch();
+    __syncthreads();
+    store8<LOG2M, 64>(lds, tid, v);
+    __syncthreads();
+    if (R4 > 1) {
+        pass4_compute<LOG2M>(lds, tid, t, v);
+        prefetch();
+        __syncthreads();
+        pass4_store<LOG2M>(lds, tid, v);
+        __syncthreads();
+    }
+}
+
+// VEC2: W == N and every frame starts 16-byte aligned, so a thread's two adjacent samples and
+// window values are one 16-byte load each.
+template <int LOG2M, bool VEC2>
+__global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fast_kernel(Params p, AnaArgs a)
+{
+    constexpr int M = FastCfg<LOG2M>::M, T = FastCfg<LOG2M>::T;
+    VOC_SMEM(double2, lds);
+    double *php = reinterpret_cast<double *>(lds + FastCfg<LOG2M>::LDS_CPLX);  // previous raw phase, K bins
+    const int tid = threadIdx.x;
+    const long long c = blockIdx.x / a.tiles;
+    const int tile = blockIdx.x % a.tiles;
+    const long long f0 = (long long)tile * a.tile_len;
+    const long long f1 = (f0 + a.tile_len < a.F) ? f0 + a.tile_len : a.F;
+    const double *xc = a.x + c * a.chan_stride;
+
+    if (f0 == 0) {
+        const double *pi = a.phase_in + c * p.K;
+        for (int k = tid; k < p.K; k += T) php[k] = pi[k];
+    }
+    // (ownership of php differs between this fill and the loop below; the barriers inside the
+    //  FFT separate them)
+
+    FastTw<LOG2M> tw;  // frame-invariant twiddle bases of this thread
+    fast_tw_init<LOG2M>(p, tid, tw);
+
+    // samples and window of frame f, even/odd packed, rewound: v[n] = padded[(n + N/2) mod N]
+    double2 xs[8];
+    auto load_frame = [&](long long f) {
+        const double *fr = xc + f * a.frame_stride;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned i0 = (unsigned)(2 * (tid + j * T) + M) & (unsigned)(2 * M - 1);  // unsigned: SGPR base + 32-bit lane offset
+            if (VEC2) {
+                xs[j] = *reinterpret_cast<const double2 *>(fr + i0);
+            } else {
+                const int j0 = (int)i0 - p.hd, j1 = j0 + 1;
+                xs[j] = make_double2((j0 >= 0 && j0 < p.W) ? fr[j0] : 0.0, (j1 >= 0 && j1 < p.W) ? fr[j1] : 0.0);
+            }
+        }
+    };
+    auto window_at = [&](int j) -> double2 {
+        const unsigned i0 = (unsigned)(2 * (tid + j * T) + M) & (unsigned)(2 * M - 1);
+        if (VEC2) return *reinterpret_cast<const double2 *>(p.window + i0);
+        const int j0 = (int)i0 - p.hd, j1 = j0 + 1;
+        return make_double2((j0 >= 0 && j0 < p.W) ? p.window[j0] : 0.0, (j1 >= 0 && j1 < p.W) ? p.window[j1] : 0.0);
+    };
+
+    const long long fs = f0 > 0 ? f0 - 1 : f0;  // one frame early to recover its raw phase
+    load_frame(fs);
+    for (long long f = fs; f < f1; ++f) {
+        const bool emit = f >= f0;
+        double2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double2 w = window_at(j);
+            v[j] = make_double2(w.x * xs[j].x, w.y * xs[j].y);
+        }
+        dft<8>(v);
+        fft_after_first<LOG2M>(lds, tw, tid, v, [&]() {
+            if (f + 1 < f1) load_frame(f + 1);
+        });
+
+        const long long row = c * a.F + f;
+        double *mrow = a.mag + row * a.ldk, *irow = a.inc + row * a.ldk;
+#pragma unroll 1
+        for (int m = 0; m < 4; ++m) {
+            const unsigned pr = tid + m * T;
+            const unsigned pe = pr == 0 ? M / 2 : pr;
+            const unsigned q = M - pe;
+            double2 Xa, Xb;
+            split_pair(lds[lds_pad(pe)], lds[lds_pad(q)], split_tw(tw.s, m, pr == 0), Xa, Xb);
+            const double pa = php[pe], pb = php[q];
+            double ma, mb, pha, phb;
+            hs_polar(Xa.x, Xa.y, ma, pha);
+            hs_polar(Xb.x, Xb.y, mb, phb);
+            if (emit) {
+                mrow[pe] = ma * a.vol;
+                mrow[q] = mb * a.vol;
+                irow[pe] = phase_inc(p, pe, pha - pa);
+                irow[q] = phase_inc(p, q, phb - pb);
+            }
+            php[pe] = pha;
+            php[q] = phb;
+        }
+        if (tid == 0) {  // DC and Nyquist bins are real: phase 0 or pi, magnitude |x|
+            const double2 z0 = lds[lds_pad(0)];
+            const double x0 = z0.x + z0.y, xm = z0.x - z0.y;
+            const double ph0 = x0 < 0.0 ? kPi : 0.0, phm = xm < 0.0 ? kPi : 0.0;
+            if (emit) {
+                mrow[0] = fabs(x0) * a.vol;
+                mrow[M] = fabs(xm) * a.vol;
+                irow[0] = phase_inc(p, 0, ph0 - php[0]);
+                irow[M] = phase_inc(p, M, phm - php[M]);
+            }
+            php[0] = ph0;
+            php[M] = phm;
+        }
+        // the next frame's first LDS write sits behind the first barrier of fft_after_first
+    }
+
+    if (f1 == a.F && f1 > f0) {
+        __syncthreads();
+        double *po = a.phase_out + c * p.K;
+        for (int k = tid; k < p.K; k += T) po[k] = php[k];
+    }
+}
+
+// OLA = false: frames out ([C][F][W]).  OLA = true: overlap-add in registers, requires W == N
+// (16 window samples per thread) and H = NH * T.
+template <int LOG2M, bool OLA, int NH>
+__global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_fast_kernel(Params p, SynArgs a)
+{
+    constexpr int M = FastCfg<LOG2M>::M, T = FastCfg<LOG2M>::T, N = 2 * M;
+    constexpr int NA = 16;  // N / T
+    VOC_SMEM(double2, lds);
+    double *php = reinterpret_cast<double *>(lds + FastCfg<LOG2M>::LDS_CPLX);  // accumulated phase, K bins
+    const double *ldsd = reinterpret_cast<const double *>(lds);
+    const int tid = threadIdx.x;
+    const long long c = blockIdx.x / a.tiles;
+    const int tile = blockIdx.x % a.tiles;
+    const long long f0 = (long long)tile * a.tile_len;
+    const long long f1 = (f0 + a.tile_len < a.F) ? f0 + a.tile_len : a.F;
+    const long long halo = OLA ? ((long long)a.halo < f0 ? (long long)a.halo : f0) : 0;
+    const long long fs = f0 - halo;
+
+    {
+        const double *pi = (tile == 0) ? a.phase_in + c * p.K : a.carry + (c * a.tiles + tile) * p.K;
+        for (int k = tid; k < p.K; k += T) php[k] = pi[k];
+    }
+    __syncthreads();
+
+    FastTw<LOG2M> tw;  // frame-invariant twiddle bases of this thread
+    fast_tw_init<LOG2M>(p, tid, tw);
+    double acc[NA];  // overlap-add partial sums of window samples tid + j*T
+#pragma unroll
+    for (int j = 0; j < NA; ++j) acc[j] = 0.0;
+
+    // STFT row of frame f: (mag, ph_inc) of this thread's eight bins, plus DC / Nyquist for thread 0
+    double mg[8], ic[8], mg0 = 0.0, mgm = 0.0, ic0 = 0.0, icm = 0.0;
+    auto load_row = [&](long long f, int lt) {
+        const double *mrow = a.mag + (c * a.F + f) * a.ldk, *irow = a.inc + (c * a.F + f) * a.ldk;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const unsigned pr = lt + m * T;
+            const unsigned pe = pr == 0 ? M / 2 : pr;
+            const unsigned q = M - pe;
+            mg[2 * m] = mrow[pe];
+            ic[2 * m] = irow[pe];
+            mg[2 * m + 1] = mrow[q];
+            ic[2 * m + 1] = irow[q];
+        }
+        if (tid == 0) {
+            mg0 = mrow[0];
+            ic0 = irow[0];
+            mgm = mrow[M];
+            icm = irow[M];
+        }
+    };
+
+    load_row(fs, tid);
+    for (long long f = fs; f < f1; ++f) {
+        const long long row = c * a.F + f;
+        const int lt = opaque_int(tid);  // keeps this frame's index arithmetic inside the loop
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const unsigned pr = lt + m * T;
+            const unsigned pe = pr == 0 ? M / 2 : pr;
+            const unsigned q = M - pe;
+            double pa = php[pe], pb = php[q];
+            const double2 A = synthesize_bin(p, mg[2 * m], ic[2 * m], pa);
+            const double2 B = synthesize_bin(p, mg[2 * m + 1], ic[2 * m + 1], pb);
+            php[pe] = pa;
+            php[q] = pb;
+            double2 Za, Zb;
+            merge_pair(A, B, split_tw(tw.s, m, pr == 0), Za, Zb);
+            lds[lds_pad(pe)] = Za;
+            lds[lds_pad(q)] = Zb;
+            sched_fence();  // one bin pair at a time: interleaving all eight sincos chains overflows the register budget
+        }
+        if (tid == 0) {  // DC and Nyquist: only the real parts enter the C2R transform
+            double p0 = php[0], pm = php[M];
+            const double2 A = synthesize_bin(p, mg0, ic0, p0);
+            const double2 B = synthesize_bin(p, mgm, icm, pm);
+            php[0] = p0;
+            php[M] = pm;
+            lds[lds_pad(0)] = make_double2(A.x - B.x, A.x + B.x);
+        }
+        __syncthreads();
+        double2 v[8];
+        load8<LOG2M>(lds, lt, v);
+        dft<8>(v);
+        double wnd[NA];  // window samples tid + j*T, fetched with the next row
+        fft_after_first<LOG2M>(lds, tw, lt, v, [&]() {
+            if (f + 1 < f1) load_row(f + 1, lt);
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const int i = lt + j * T;
+                wnd[j] = p.window[(unsigned)(OLA ? i : (i < p.W ? i : p.W - 1))];  // OLA: W == N, always in range
+            }
+        });
+        // lds[pad(m)] = swapped z[m]: v[2m] = z.y / N, v[2m+1] = z.x / N.  frame[i] = w[i] * v[(i + off + N/2) mod N]
+        const bool emit = f >= f0;
+        if (OLA) {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const int n = (lt + j * T + M) & (N - 1);  // W == N: off = 0
+                const double s = ldsd[2 * lds_pad(n >> 1) + ((n & 1) ^ 1)] * p.inv_n;
+                acc[j] = acc[j] + wnd[j] * s;
+            }
+            if (emit) {
+                double *yc = a.out + c * a.out_stride + f * p.H;
+#pragma unroll
+                for (int j = 0; j < NH; ++j) yc[(unsigned)(lt + j * T)] = acc[j];
+            }
+#pragma unroll
+            for (int j = 0; j < NA; ++j) acc[j] = (j + NH < NA) ? acc[j + NH] : 0.0;
+        } else {
+            double *fo = a.out + row * p.W;
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const int i = lt + j * T;
+                const int n = (i + p.off + M) & (N - 1);
+                const double s = ldsd[2 * lds_pad(n >> 1) + ((n & 1) ^ 1)] * p.inv_n;
+                if (i < p.W) fo[i] = wnd[j] * s;
+            }
+        }
+        __syncthreads();  // FFT buffer is rewritten by the next frame's spectrum
+    }
+
+    if (f1 == a.F && f1 > f0) {
+        double *po = a.phase_out + c * p.K;
+        for (int k = tid; k < p.K; k += T) po[k] = php[k];  // php is stable: last barrier passed
+        if (OLA) {
+            // tail after the last frame: the remaining N - H partial sums, then the zero padding of
+            // the last chunk (sumFramesE, Frames.hs:45-47)
+            double *yc = a.out + c * a.out_stride;
+            const long long start = a.F * p.H;
+#pragma unroll
+            for (int j = 0; j < NA - NH; ++j) {
+                const long long pos = start + tid + j * T;
+                if (pos < a.out_len) yc[pos] = acc[j];
+            }
+            for (long long pos = start + (NA - NH) * T + tid; pos < a.out_len; pos += T) yc[pos] = 0.0;
+        }
+    }
+}
+
+}  // namespace voc

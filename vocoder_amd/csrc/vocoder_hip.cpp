@@ -16,6 +16,7 @@
 
 #include "../../include/vocoder_hip.h"
 #include "voc_kernels.h"
+#include "voc_kernels_fast.h"
 
 #define VOC_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -24,11 +25,12 @@ struct voc_ctx {
     std::vector<double> window;
     double vol = 0.0;
     double *d_window = nullptr;
-    double2 *d_twM = nullptr, *d_twS = nullptr;
+    double2 *d_twP = nullptr, *d_twS = nullptr;
     voc::Params params{};
     void *ws = nullptr;
     size_t ws_bytes = 0;
     int ana_tile_override = 0, syn_tile_override = 0;
+    bool force_generic = false;  // VOC_FORCE_GENERIC=1: never take the specialised kernels
 #ifndef VOC_EMU
     bool profiling = false;
     struct Timed { int kind; hipEvent_t start, stop; };
@@ -159,6 +161,86 @@ void launch_synthesis(voc_ctx *c, const voc::SynArgs &a, long long channels, hip
     HIPCHK(hipGetLastError());
 }
 
+#define VOC_FOR_EACH_FAST_LOG2M(X) X(9) X(10) X(11) X(12)
+
+inline bool fast_sizes(const voc_ctx *c) { return !c->force_generic && c->log2m >= 9 && c->log2m <= 12; }
+
+// Specialised analysis kernel (polar output) when the frame length allows it.
+bool launch_analysis_fast(voc_ctx *c, const voc::AnaArgs &a, long long channels, hipStream_t st)
+{
+    if (!fast_sizes(c)) return false;
+    const long long grid = channels * a.tiles;
+    if (grid <= 0) return true;
+    if (grid > 0x7fffffffLL) throw HipFail{hipErrorInvalidValue, "analysis grid too large"};
+    const bool vec2 = c->W == c->N && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0) && a.chan_stride % 2 == 0 &&
+                      a.frame_stride % 2 == 0;
+    LaunchTimer timer(c, KIND_ANALYSIS, st);
+    switch (c->log2m) {
+#define X(L)                                                                                                   \
+    case L:                                                                                                    \
+        if (vec2)                                                                                              \
+            hipLaunchKernelGGL((voc::analysis_fast_kernel<L, true>), dim3((unsigned)grid),                     \
+                               dim3(voc::FastCfg<L>::T), voc::FastCfg<L>::LDS_BYTES, st, c->params, a);        \
+        else                                                                                                   \
+            hipLaunchKernelGGL((voc::analysis_fast_kernel<L, false>), dim3((unsigned)grid),                    \
+                               dim3(voc::FastCfg<L>::T), voc::FastCfg<L>::LDS_BYTES, st, c->params, a);        \
+        break;
+        VOC_FOR_EACH_FAST_LOG2M(X)
+#undef X
+    }
+    HIPCHK(hipGetLastError());
+    return true;
+}
+
+// The register-resident overlap-add needs W == N (16 window samples per thread) and a hop that is
+// a multiple of the thread count.
+inline int fast_ola_nh(const voc_ctx *c)
+{
+    if (!fast_sizes(c) || c->W != c->N) return 0;
+    const int t = c->M / 8;
+    if (c->H % t != 0) return 0;
+    const int nh = c->H / t;
+    return (nh == 1 || nh == 2 || nh == 4 || nh == 8 || nh == 16) ? nh : 0;
+}
+
+template <int L, bool OLA>
+void launch_synthesis_fast_nh(voc_ctx *c, const voc::SynArgs &a, unsigned grid, int nh, hipStream_t st)
+{
+    const dim3 g(grid), b(voc::FastCfg<L>::T);
+    const size_t lds = voc::FastCfg<L>::LDS_BYTES;
+    switch (nh) {
+    case 1: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 1>), g, b, lds, st, c->params, a); break;
+    case 2: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 2>), g, b, lds, st, c->params, a); break;
+    case 4: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 4>), g, b, lds, st, c->params, a); break;
+    case 8: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 8>), g, b, lds, st, c->params, a); break;
+    default: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 16>), g, b, lds, st, c->params, a); break;
+    }
+}
+
+// Specialised synthesis kernel (polar input): frames out, or overlap-add out when fast_ola_nh() != 0.
+bool launch_synthesis_fast(voc_ctx *c, const voc::SynArgs &a, long long channels, bool ola, hipStream_t st)
+{
+    if (!fast_sizes(c)) return false;
+    const int nh = ola ? fast_ola_nh(c) : 16;
+    if (ola && nh == 0) return false;
+    const long long grid = channels * a.tiles;
+    if (grid <= 0) return true;
+    if (grid > 0x7fffffffLL) throw HipFail{hipErrorInvalidValue, "synthesis grid too large"};
+    LaunchTimer timer(c, KIND_SYNTHESIS, st);
+    switch (c->log2m) {
+#define X(L)                                                                          \
+    case L:                                                                           \
+        if (ola) launch_synthesis_fast_nh<L, true>(c, a, (unsigned)grid, nh, st);     \
+        else hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, false, 16>), dim3((unsigned)grid), \
+                                dim3(voc::FastCfg<L>::T), voc::FastCfg<L>::LDS_BYTES, st, c->params, a); \
+        break;
+        VOC_FOR_EACH_FAST_LOG2M(X)
+#undef X
+    }
+    HIPCHK(hipGetLastError());
+    return true;
+}
+
 inline unsigned ew_grid(long long total)
 {
     long long g = (total + 255) / 256;
@@ -188,7 +270,7 @@ void synthesis_tiling(const voc_ctx *c, long long channels, long long F, int hal
     if (c->syn_tile_override > 0) {
         tl = c->syn_tile_override;
     } else {
-        long long want = (1024 + channels - 1) / channels;  // tiles per channel to reach ~1024 workgroups
+        long long want = (3072 + channels - 1) / channels;  // tiles per channel to reach ~3072 workgroups (4 rounds of 3 per CU)
         long long min_tile = 8LL * (halo + 1);
         if (min_tile < 16) min_tile = 16;
         long long max_tiles = F / min_tile;
@@ -257,7 +339,7 @@ void analysis_stage_dev(voc_ctx *c, double *phase_io, const double *frames, doub
     a.tile_len = analysis_tile_len(c, C, F);
     a.tiles = (int)((F + a.tile_len - 1) / a.tile_len);
     a.vol = 1.0;
-    launch_analysis<false, false>(c, a, C, st);
+    if (!launch_analysis_fast(c, a, C, st)) launch_analysis<false, false>(c, a, C, st);
 }
 
 void synthesis_stage_dev(voc_ctx *c, double *phase_io, const double *mag, const double *inc, double *frames,
@@ -291,7 +373,7 @@ void synthesis_stage_dev(voc_ctx *c, double *phase_io, const double *mag, const 
     a.tile_len = tile_len;
     a.tiles = tiles;
     a.halo = 0;
-    launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_FRAMES>(c, a, C, st);
+    if (!launch_synthesis_fast(c, a, C, false, st)) launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_FRAMES>(c, a, C, st);
 }
 
 struct RtPlan {
@@ -380,7 +462,7 @@ void roundtrip_dev(voc_ctx *c, const double *x, long long x_stride, long long le
         a.tile_len = r.ana_tile;
         a.tiles = r.ana_tiles;
         a.vol = c->vol;  // volumeFix folded into the magnitude store (Conduit.hs:34-35)
-        launch_analysis<false, false>(c, a, G, st);
+        if (!launch_analysis_fast(c, a, G, st)) launch_analysis<false, false>(c, a, G, st);
 
         if (r.syn_tiles > 1) {
             const long long chains = G * c->K;
@@ -404,11 +486,11 @@ void roundtrip_dev(voc_ctx *c, const double *x, long long x_stride, long long le
         s.tiles = r.syn_tiles;
         s.halo = r.halo;
         if (r.fused_ola) {
-            launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_OLA>(c, s, G, st);
+            if (!launch_synthesis_fast(c, s, G, true, st)) launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_OLA>(c, s, G, st);
         } else {
             // frame too long for an LDS-resident overlap-add ring: frames go through HBM once
             s.out = frames;
-            launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_FRAMES>(c, s, G, st);
+            if (!launch_synthesis_fast(c, s, G, false, st)) launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_FRAMES>(c, s, G, st);
             const long long total = G * r.out_len;
             hipLaunchKernelGGL(voc::sum_frames_kernel, dim3(ew_grid(total)), dim3(256), 0, st, frames, F, c->W, c->H,
                                y + c0 * y_stride, (long long)y_stride, r.out_len, total);
@@ -468,22 +550,33 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
         c->vol = (double)H / s;
         c->ana_tile_override = env_int("VOC_ANA_TILE_LEN");
         c->syn_tile_override = env_int("VOC_SYN_TILE_LEN");
+        c->force_generic = env_int("VOC_FORCE_GENERIC") != 0;
 
-        std::vector<double2> twM((size_t)c->M), twS((size_t)c->M / 2 + 1);
+        // per-pass Stockham twiddles, laid out as voc::fft_passes reads them: the pass at stride NS
+        // (radix r = min(8, M/NS)) occupies entries NS-1 .. NS-1 + (r-1)*NS, [j-1][k] with k fastest,
+        // value exp(-2 pi i j k / (NS r))
+        std::vector<double2> twP((size_t)c->M), twS((size_t)c->M / 2 + 1);
         const long double two_pi = 2.0L * 3.141592653589793238462643383279502884L;
-        for (int m = 0; m < c->M; ++m) {
-            const long double ang = two_pi * (long double)m / (long double)c->M;
-            twM[m] = make_double2((double)cosl(ang), (double)-sinl(ang));
+        for (int ns = 1; ns < c->M;) {
+            const int rad = (c->M / ns) >= 8 ? 8 : (c->M / ns);
+            if (ns > 1)
+                for (int j = 1; j < rad; ++j)
+                    for (int k = 0; k < ns; ++k) {
+                        const long double ang = two_pi * (long double)((long long)j * k) / (long double)((long long)ns * rad);
+                        twP[(size_t)(ns - 1) + (size_t)(j - 1) * ns + k] = make_double2((double)cosl(ang), (double)-sinl(ang));
+                    }
+            ns *= rad;
         }
         for (int k = 0; k <= c->M / 2; ++k) {
             const long double ang = two_pi * (long double)k / (long double)N;
             twS[k] = make_double2((double)cosl(ang), (double)-sinl(ang));
         }
+        twS[c->M / 2] = make_double2(0.0, -1.0);  // exp(-i pi/2) exactly
         HIPCHK(hipMalloc((void **)&c->d_window, sizeof(double) * (size_t)W));
-        HIPCHK(hipMalloc((void **)&c->d_twM, sizeof(double2) * twM.size()));
+        HIPCHK(hipMalloc((void **)&c->d_twP, sizeof(double2) * twP.size()));
         HIPCHK(hipMalloc((void **)&c->d_twS, sizeof(double2) * twS.size()));
         HIPCHK(hipMemcpy(c->d_window, window, sizeof(double) * (size_t)W, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(c->d_twM, twM.data(), sizeof(double2) * twM.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_twP, twP.data(), sizeof(double2) * twP.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->d_twS, twS.data(), sizeof(double2) * twS.size(), hipMemcpyHostToDevice));
 
         voc::Params &p = c->params;
@@ -496,7 +589,7 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
         p.inv_hop = 1.0 / (double)H;
         p.inv_n = 1.0 / (double)N;
         p.window = c->d_window;
-        p.twM = c->d_twM;
+        p.twP = c->d_twP;
         p.twS = c->d_twS;
         return VOC_OK;
     });
@@ -514,7 +607,7 @@ VOC_EXPORT int32_t voc_ctx_destroy(voc_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->ws) { (void)hipDeviceSynchronize(); (void)hipFree(c->ws); }
     if (c->d_window) (void)hipFree(c->d_window);
-    if (c->d_twM) (void)hipFree(c->d_twM);
+    if (c->d_twP) (void)hipFree(c->d_twP);
     if (c->d_twS) (void)hipFree(c->d_twS);
     delete c;
     return VOC_OK;
