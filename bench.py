@@ -25,7 +25,6 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 N_FFT, HOP, RATE, SECONDS = 4096, 1024, 48000, 60
 HBM_PEAK = 8.0e12                                  # B/s, MI355X HBM3E
@@ -80,9 +79,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    from vocoder_amd import distributed as D
+    D.init("nccl", dev)
 
     from vocoder_amd import vocoder as V, conduit as Cd, window as Wn
     win = Wn.hann_window(N_FFT)
@@ -101,8 +99,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        D.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -118,10 +115,7 @@ def main():
     ms = (np.zeros(4), np.zeros(4, dtype=np.int64))
     par.lib.check(par.lib.dll.voc_profile_read(par.handle, ms[0].ctypes.data, ms[1].ctypes.data))
     par.lib.check(par.lib.dll.voc_profile_enable(par.handle, 0))
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    dt = D.max_over_ranks(dt, dev)
 
     if rank == 0:
         value = frames * world * args.steps / dt
@@ -156,8 +150,7 @@ def main():
                                    "sample": f"{ncpu} of the {c} streams x 60 s ({nfr} frames, {secs:.1f} s of CPU time), "
                                              "C restatement of the reference path"}
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    D.finish()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,152 @@
+{-|
+Module      : Vocoder.HIP
+Description : The @Vocoder@ core API on top of libvocoder_hip.so
+
+Drop-in definitions for the part of vocoder/src/Vocoder.hs that touches the FFT binding.  Types
+and names are the reference's (Vocoder.hs:54-111); only their bodies change:
+
+  * 'VocoderParams' holds a 'ForeignPtr' to the library context instead of two FFTW plans
+    (Vocoder.hs:89-99); 'vocoderParams' has the same signature (Vocoder.hs:114-115).
+  * 'analysisStage' / 'synthesisStage' (Vocoder.hs:149-150,177-178) marshal the whole
+    @Traversable@ of frames into one contiguous buffer and cross the FFI once;
+    'analysisBlock' / 'synthesisBlock' (Vocoder.hs:153-154,181-182) are the one-frame case.
+  * a non-zero status becomes 'error', as the reference does for bad sizes (Vocoder.hs:132) and as
+    vector-fftw's @execute@ does for a length mismatch.
+
+vocoder-conduit and vocoder-dunai need no source change: they only use the names re-exported here
+(Conduit.hs:39,43,64,68; Dunai.hs:30,34).  Could not be compiled where it was written (no GHC).
+-}
+module Vocoder.HIP
+    ( VocoderParams, vocoderParams, vocFrameLength, vocInputFrameLength, vocFreqFrameLength
+    , vocHopSize, vocWindow, analysisStage, analysisBlock, synthesisStage, synthesisBlock
+    , zeroPhase, volumeCoeff, processChannels
+    ) where
+
+import Control.Monad (when)
+import Data.Int (Int32)
+import Data.Foldable (toList)
+import Data.Traversable (mapAccumL)
+import qualified Data.Vector.Storable as V
+import qualified Data.Vector.Storable.Mutable as MV
+import Foreign.C.String (peekCString)
+import Foreign.ForeignPtr
+import Foreign.Marshal.Alloc (alloca)
+import Foreign.Ptr
+import Foreign.Storable (peek)
+import System.IO.Unsafe (unsafePerformIO)
+import Vocoder.HIP.FFI
+
+type Moduli = V.Vector Double
+type Phase = V.Vector Double
+type PhaseInc = V.Vector Double
+type Frame = V.Vector Double
+type Window = Frame
+type STFTFrame = (Moduli, PhaseInc)
+
+data VocoderParams = VocoderParams
+    { vocCtx :: ForeignPtr VocCtx
+    , vocFrameLength :: Int
+    , vocHopSize :: Int
+    , vocWindow :: Window
+    }
+
+vocInputFrameLength :: VocoderParams -> Int
+vocInputFrameLength = V.length . vocWindow
+
+vocFreqFrameLength :: VocoderParams -> Int
+vocFreqFrameLength par = vocFrameLength par `div` 2 + 1
+
+-- | A non-zero status becomes `error`, the reference's own convention (Vocoder.hs:132).
+check :: String -> IO Int32 -> IO ()
+check what act = do
+    st <- act
+    when (st /= 0) $ do
+        msg <- c_voc_strerror st >>= peekCString
+        error (what ++ ": " ++ msg)
+
+-- | vocoderParams len hop window (Vocoder.hs:114-115)
+vocoderParams :: Int -> Int -> Window -> VocoderParams
+vocoderParams len hs wnd = unsafePerformIO $
+    V.unsafeWith wnd $ \pw -> alloca $ \pout -> do
+        check "vocoderParams" $
+            c_voc_ctx_create (fromIntegral len) (fromIntegral hs) pw (fromIntegral (V.length wnd)) 0 0 pout
+        ctx <- peek pout >>= newForeignPtr p_voc_ctx_destroy
+        return (VocoderParams ctx len hs wnd)
+{-# NOINLINE vocoderParams #-}
+
+zeroPhase :: VocoderParams -> Phase
+zeroPhase par = V.replicate (vocFreqFrameLength par) 0
+
+volumeCoeff :: VocoderParams -> Double
+volumeCoeff par = unsafePerformIO $ withForeignPtr (vocCtx par) c_voc_volume_coeff
+
+-- | analysisStage (Vocoder.hs:149-150): one FFI call for the whole container of frames.
+analysisStage :: Traversable t => VocoderParams -> Phase -> t Frame -> (Phase, t STFTFrame)
+analysisStage par ph frs = unsafePerformIO $ do
+    let fl = toList frs
+        f = length fl
+        k = vocFreqFrameLength par
+    phm <- V.thaw ph
+    mag <- MV.new (f * k)
+    inc <- MV.new (f * k)
+    withForeignPtr (vocCtx par) $ \ctx ->
+        V.unsafeWith (V.concat fl) $ \pfr -> MV.unsafeWith phm $ \pph ->
+        MV.unsafeWith mag $ \pm -> MV.unsafeWith inc $ \pin ->
+            check "analysisStage" $ c_voc_analysis_stage ctx pph pfr pm pin 1 (fromIntegral f)
+    ph' <- V.freeze phm
+    magv <- V.unsafeFreeze mag
+    incv <- V.unsafeFreeze inc
+    let slice v i = V.slice (i * k) k v
+        (_, out) = mapAccumL (\i _ -> (i + 1, (slice magv i, slice incv i))) 0 frs
+    return (ph', out)
+
+analysisBlock :: VocoderParams -> Phase -> Frame -> (Phase, STFTFrame)
+analysisBlock par ph fr = let (ph', [r]) = analysisStage par ph [fr] in (ph', r)
+
+-- | synthesisStage (Vocoder.hs:177-178)
+synthesisStage :: Traversable t => VocoderParams -> Phase -> t STFTFrame -> (Phase, t Frame)
+synthesisStage par ph frs = unsafePerformIO $ do
+    let fl = toList frs
+        f = length fl
+        w = vocInputFrameLength par
+    phm <- V.thaw ph
+    out <- MV.new (f * w)
+    withForeignPtr (vocCtx par) $ \ctx ->
+        V.unsafeWith (V.concat (map fst fl)) $ \pm -> V.unsafeWith (V.concat (map snd fl)) $ \pin ->
+        MV.unsafeWith phm $ \pph -> MV.unsafeWith out $ \po ->
+            check "synthesisStage" $ c_voc_synthesis_stage ctx pph pm pin po 1 (fromIntegral f)
+    ph' <- V.freeze phm
+    outv <- V.unsafeFreeze out
+    let (_, res) = mapAccumL (\i _ -> (i + 1, V.slice (i * w) w outv)) 0 frs
+    return (ph', res)
+
+synthesisBlock :: VocoderParams -> Phase -> STFTFrame -> (Phase, Frame)
+synthesisBlock par ph fr = let (ph', [r]) = synthesisStage par ph [fr] in (ph', r)
+
+-- | The fused path of Vocoder.Conduit.process with the identity filter, for C planar channels
+--   of equal length: (leftover ++ input per channel, phases) -> (output, leftover', phases').
+processChannels :: VocoderParams -> Int -> [V.Vector Double] -> ([Phase], [Phase])
+                -> ([V.Vector Double], [V.Vector Double], ([Phase], [Phase]))
+processChannels par chunk xs (aphs, sphs) = unsafePerformIO $ do
+    let c = length xs
+        len = V.length (head xs)
+        k = vocFreqFrameLength par
+    withForeignPtr (vocCtx par) $ \ctx -> do
+        nf <- c_voc_num_frames ctx (fromIntegral len)
+        ol <- fromIntegral <$> c_voc_ola_length ctx nf (fromIntegral chunk)
+        keep <- fromIntegral <$> c_voc_leftover_length ctx (fromIntegral len)
+        y <- MV.new (c * ol)
+        left <- MV.new (c * max 1 keep)
+        am <- V.thaw (V.concat aphs)
+        sm <- V.thaw (V.concat sphs)
+        V.unsafeWith (V.concat xs) $ \px -> MV.unsafeWith y $ \py -> MV.unsafeWith am $ \pa ->
+            MV.unsafeWith sm $ \ps -> MV.unsafeWith left $ \pl ->
+                check "processChannels" $
+                    c_voc_roundtrip ctx px (fromIntegral len) (fromIntegral len) (fromIntegral c)
+                        (fromIntegral chunk) py (fromIntegral ol) pa ps pl (fromIntegral keep)
+        yv <- V.unsafeFreeze y
+        lv <- V.unsafeFreeze left
+        av <- V.unsafeFreeze am
+        sv <- V.unsafeFreeze sm
+        let rows n v = [V.slice (i * n) n v | i <- [0 .. c - 1]]
+        return (rows ol yv, rows keep lv, (rows k av, rows k sv))

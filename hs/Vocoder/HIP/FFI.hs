@@ -1,0 +1,64 @@
+{-# LANGUAGE ForeignFunctionInterface #-}
+{-|
+Module      : Vocoder.HIP.FFI
+Description : Raw bindings to libvocoder_hip.so (include/vocoder_hip.h)
+
+The binding a maintainer of the @vocoder@ package adds to move the STFT path to an MI355X.  It
+stands where @Numeric.FFT.Vector.Invertible@ / @Numeric.FFT.Vector.Plan@ stand today
+(vocoder/src/Vocoder.hs:49-50).  This file could not be compiled where it was written (no GHC
+there); the C ABI it binds is exercised by the C++ and Python hosts instead.
+
+Stage and round-trip calls block for milliseconds, so they are imported @safe@; the accessors are
+@unsafe@.  A @voc_ctx@ is internally locked, so calls may come from any capability.
+-}
+module Vocoder.HIP.FFI where
+
+import Data.Int
+import Foreign.C.String
+import Foreign.C.Types
+import Foreign.Ptr
+
+data VocCtx
+
+foreign import ccall unsafe "voc_strerror"        c_voc_strerror :: Int32 -> IO CString
+foreign import ccall unsafe "voc_last_hip_error"  c_voc_last_hip_error :: Ptr VocCtx -> IO CString
+foreign import ccall safe   "voc_ctx_create"      c_voc_ctx_create
+    :: Int32 -> Int32 -> Ptr Double -> Int32 -> Int32 -> Int32 -> Ptr (Ptr VocCtx) -> IO Int32
+foreign import ccall safe   "voc_ctx_destroy"     c_voc_ctx_destroy :: Ptr VocCtx -> IO Int32
+foreign import ccall unsafe "&voc_ctx_destroy"    p_voc_ctx_destroy :: FunPtr (Ptr VocCtx -> IO ())
+foreign import ccall unsafe "voc_frame_length"       c_voc_frame_length :: Ptr VocCtx -> IO Int32
+foreign import ccall unsafe "voc_input_frame_length" c_voc_input_frame_length :: Ptr VocCtx -> IO Int32
+foreign import ccall unsafe "voc_freq_frame_length"  c_voc_freq_frame_length :: Ptr VocCtx -> IO Int32
+foreign import ccall unsafe "voc_hop_size"           c_voc_hop_size :: Ptr VocCtx -> IO Int32
+foreign import ccall unsafe "voc_volume_coeff"       c_voc_volume_coeff :: Ptr VocCtx -> IO Double
+
+foreign import ccall safe "voc_r2c"     c_voc_r2c     :: Ptr VocCtx -> Ptr Double -> Ptr Double -> Int64 -> IO Int32
+foreign import ccall safe "voc_c2r"     c_voc_c2r     :: Ptr VocCtx -> Ptr Double -> Ptr Double -> Int64 -> IO Int32
+foreign import ccall safe "voc_do_fft"  c_voc_do_fft  :: Ptr VocCtx -> Ptr Double -> Ptr Double -> Int64 -> IO Int32
+foreign import ccall safe "voc_do_ifft" c_voc_do_ifft :: Ptr VocCtx -> Ptr Double -> Ptr Double -> Int64 -> IO Int32
+
+foreign import ccall safe "voc_analysis_step" c_voc_analysis_step
+    :: Ptr VocCtx -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Int64 -> IO Int32
+foreign import ccall safe "voc_synthesis_step" c_voc_synthesis_step
+    :: Ptr VocCtx -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Int64 -> IO Int32
+foreign import ccall safe "voc_add_frames" c_voc_add_frames
+    :: Ptr VocCtx -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Int64 -> IO Int32
+
+-- | phase_io[C*K], frames[C*F*W], mag[C*F*K], ph_inc[C*F*K], channels, frames
+foreign import ccall safe "voc_analysis_stage" c_voc_analysis_stage
+    :: Ptr VocCtx -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Int64 -> Int64 -> IO Int32
+foreign import ccall safe "voc_synthesis_stage" c_voc_synthesis_stage
+    :: Ptr VocCtx -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Int64 -> Int64 -> IO Int32
+
+foreign import ccall unsafe "voc_num_frames"      c_voc_num_frames :: Ptr VocCtx -> Int64 -> IO Int64
+foreign import ccall unsafe "voc_leftover_length" c_voc_leftover_length :: Ptr VocCtx -> Int64 -> IO Int64
+foreign import ccall unsafe "voc_ola_length"      c_voc_ola_length :: Ptr VocCtx -> Int64 -> Int64 -> IO Int64
+foreign import ccall safe "voc_frames_of" c_voc_frames_of
+    :: Ptr VocCtx -> Ptr Double -> Int64 -> Int64 -> Int64 -> Ptr Double -> IO Int32
+foreign import ccall safe "voc_sum_frames" c_voc_sum_frames
+    :: Ptr VocCtx -> Ptr Double -> Int64 -> Int64 -> Int64 -> Ptr Double -> Int64 -> IO Int32
+
+-- | x, x_stride, length, channels, chunk, y, y_stride, ana_phase_io, syn_phase_io, leftover, leftover_stride
+foreign import ccall safe "voc_roundtrip" c_voc_roundtrip
+    :: Ptr VocCtx -> Ptr Double -> Int64 -> Int64 -> Int64 -> Int64 -> Ptr Double -> Int64
+    -> Ptr Double -> Ptr Double -> Ptr Double -> Int64 -> IO Int32

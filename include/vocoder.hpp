@@ -1,0 +1,113 @@
+// vocoder.hpp -- C++ host-side mirror of the reference's `Vocoder` module
+// (vocoder/src/Vocoder.hs:12-42) over the C ABI in vocoder_hip.h.  Header only.
+//
+// The reference is compiled Haskell; where its toolchain is absent this is the host language
+// the path is used from.  Names, argument meaning and error behaviour follow the reference: a
+// failing call throws std::runtime_error where the reference calls `error` (Vocoder.hs:132).
+#pragma once
+
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "vocoder_hip.h"
+
+namespace vocoder {
+
+using Frame = std::vector<double>;     // Vocoder.hs:65
+using Window = Frame;                  // Vocoder.hs:68
+using Phase = std::vector<double>;     // Vocoder.hs:57
+using Moduli = std::vector<double>;    // Vocoder.hs:54
+using PhaseInc = std::vector<double>;  // Vocoder.hs:62
+struct STFTFrames {                    // a run of STFTFrame = (Moduli, PhaseInc), Vocoder.hs:77, F x K each
+    std::vector<double> mag, ph_inc;
+};
+
+inline void check(int32_t st, const char *what, const voc_ctx *ctx = nullptr)
+{
+    if (st == VOC_OK) return;
+    std::string msg = std::string(what) + ": " + voc_strerror(st);
+    if (ctx && st == VOC_ERR_HIP) msg += std::string(" (") + voc_last_hip_error(ctx) + ")";
+    throw std::runtime_error(msg);
+}
+
+// VocoderParams (Vocoder.hs:89-99) / vocoderParams len hop window (Vocoder.hs:114-115)
+class VocoderParams {
+public:
+    VocoderParams(int length, int hop, const Window &window, int device = 0)
+    {
+        check(voc_ctx_create(length, hop, window.data(), (int32_t)window.size(), device, VOC_PRECISION_F64, &ctx_),
+              "vocoderParams");
+    }
+    ~VocoderParams() { voc_ctx_destroy(ctx_); }
+    VocoderParams(const VocoderParams &) = delete;
+    VocoderParams &operator=(const VocoderParams &) = delete;
+
+    int vocFrameLength() const { return voc_frame_length(ctx_); }             // Vocoder.hs:106-107
+    int vocInputFrameLength() const { return voc_input_frame_length(ctx_); }  // Vocoder.hs:110-111
+    int vocFreqFrameLength() const { return voc_freq_frame_length(ctx_); }    // Vocoder.hs:102-103
+    int vocHopSize() const { return voc_hop_size(ctx_); }                     // Vocoder.hs:95
+    double volumeCoeff() const { return voc_volume_coeff(ctx_); }             // Vocoder.hs:209-210
+    Phase zeroPhase() const { return Phase((size_t)vocFreqFrameLength(), 0.0); }  // Vocoder.hs:204-205
+    voc_ctx *handle() const { return ctx_; }
+
+private:
+    voc_ctx *ctx_ = nullptr;
+};
+
+// analysisStage par ph frames -> (ph', stft)  (Vocoder.hs:149-150); frames is F x W, row major
+inline std::pair<Phase, STFTFrames> analysisStage(const VocoderParams &par, Phase ph, const std::vector<double> &frames)
+{
+    const size_t w = (size_t)par.vocInputFrameLength(), k = (size_t)par.vocFreqFrameLength();
+    if (frames.size() % w) throw std::runtime_error("analysisStage: size mismatch");
+    const size_t f = frames.size() / w;
+    STFTFrames out{std::vector<double>(f * k), std::vector<double>(f * k)};
+    check(voc_analysis_stage(par.handle(), ph.data(), frames.data(), out.mag.data(), out.ph_inc.data(), 1, (int64_t)f),
+          "analysisStage", par.handle());
+    return {std::move(ph), std::move(out)};
+}
+
+// synthesisStage par ph stft -> (ph', frames)  (Vocoder.hs:177-178)
+inline std::pair<Phase, std::vector<double>> synthesisStage(const VocoderParams &par, Phase ph, const STFTFrames &stft)
+{
+    const size_t w = (size_t)par.vocInputFrameLength(), k = (size_t)par.vocFreqFrameLength();
+    const size_t f = stft.mag.size() / k;
+    std::vector<double> frames(f * w);
+    check(voc_synthesis_stage(par.handle(), ph.data(), stft.mag.data(), stft.ph_inc.data(), frames.data(), 1, (int64_t)f),
+          "synthesisStage", par.handle());
+    return {std::move(ph), std::move(frames)};
+}
+
+// analysisBlock / synthesisBlock (Vocoder.hs:153-154,181-182): the one-frame case
+inline std::pair<Phase, STFTFrames> analysisBlock(const VocoderParams &par, Phase ph, const Frame &frame)
+{
+    return analysisStage(par, std::move(ph), frame);
+}
+inline std::pair<Phase, Frame> synthesisBlock(const VocoderParams &par, Phase ph, const STFTFrames &one)
+{
+    return synthesisStage(par, std::move(ph), one);
+}
+
+struct Processed {
+    std::vector<double> y, leftover;  // C x out_len, C x keep (planar)
+    std::vector<double> ana_phase, syn_phase;
+};
+
+// One `processWith q phs idFilter` step of Vocoder.Conduit (Conduit.hs:46-53) for C planar channels:
+// x holds (previous leftover ++ new samples) per channel, `length` samples each.
+inline Processed process(const VocoderParams &par, const std::vector<double> &x, int64_t channels, int64_t chunk,
+                         std::vector<double> ana_phase, std::vector<double> syn_phase)
+{
+    const int64_t len = channels ? (int64_t)x.size() / channels : 0;
+    const int64_t f = voc_num_frames(par.handle(), len), n = voc_ola_length(par.handle(), f, chunk),
+                  keep = voc_leftover_length(par.handle(), len);
+    Processed r{std::vector<double>((size_t)(channels * n)), std::vector<double>((size_t)(channels * keep)),
+                std::move(ana_phase), std::move(syn_phase)};
+    check(voc_roundtrip(par.handle(), x.data(), len, len, channels, chunk, r.y.data(), n, r.ana_phase.data(),
+                        r.syn_phase.data(), r.leftover.data(), keep),
+          "process", par.handle());
+    return r;
+}
+
+}  // namespace vocoder
