@@ -354,13 +354,18 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
     }
 }
 
-// OLA = false: frames out ([C][F][W]).  OLA = true: overlap-add in registers, requires W == N
-// (16 window samples per thread) and H = NH * T.
-template <int LOG2M, bool OLA, int NH>
+// OLA = false: frames out ([C][F][W]).
+// OLA = true: overlap-add in registers.  Requires W == N and H = NHP * 2T: thread t owns the sample
+// PAIRS (2(t + jT), 2(t + jT) + 1), j = 0..7, of the N-sample window -- one complex LDS element,
+// one 16-byte window load and one 16-byte store per pair -- and the partial sums shift by NHP
+// pairs per frame.  y rows must be 16-byte aligned.
+template <int LOG2M, bool OLA, int NHP>
 __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_fast_kernel(Params p, SynArgs a)
 {
     constexpr int M = FastCfg<LOG2M>::M, T = FastCfg<LOG2M>::T, N = 2 * M;
-    constexpr int NA = 16;  // N / T
+    constexpr int NP = 8;                       // sample pairs per thread
+    constexpr int NK = OLA ? NP - NHP : 0;      // pairs whose partial sums outlive the frame
+    constexpr int NT = NK > 0 ? NK : 1;         // (array length: never zero)
     VOC_SMEM(double2, lds);
     double *php = reinterpret_cast<double *>(lds + FastCfg<LOG2M>::LDS_CPLX);  // accumulated phase, K bins
     const double *ldsd = reinterpret_cast<const double *>(lds);
@@ -380,9 +385,9 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
 
     FastTw<LOG2M> tw;  // frame-invariant twiddle bases of this thread
     fast_tw_init<LOG2M>(p, tid, tw);
-    double acc[NA];  // overlap-add partial sums of window samples tid + j*T
+    double2 tail[NT];  // overlap-add partial sums that later frames still add to
 #pragma unroll
-    for (int j = 0; j < NA; ++j) acc[j] = 0.0;
+    for (int j = 0; j < NT; ++j) tail[j] = make_double2(0.0, 0.0);
 
     // STFT row of frame f: (mag, ph_inc) of this thread's eight bins, plus DC / Nyquist for thread 0
     double mg[8], ic[8], mg0 = 0.0, mgm = 0.0, ic0 = 0.0, icm = 0.0;
@@ -438,39 +443,40 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
         double2 v[8];
         load8<LOG2M>(lds, lt, v);
         dft<8>(v);
-        double wnd[NA];  // window samples tid + j*T, fetched with the next row
         fft_after_first<LOG2M>(lds, tw, lt, v, [&]() {
             if (f + 1 < f1) load_row(f + 1, lt);
-#pragma unroll
-            for (int j = 0; j < NA; ++j) {
-                const int i = lt + j * T;
-                wnd[j] = p.window[(unsigned)(OLA ? i : (i < p.W ? i : p.W - 1))];  // OLA: W == N, always in range
-            }
         });
         // lds[pad(m)] = swapped z[m]: v[2m] = z.y / N, v[2m+1] = z.x / N.  frame[i] = w[i] * v[(i + off + N/2) mod N]
         const bool emit = f >= f0;
         if (OLA) {
+            // W == N (off = 0): window samples 2i, 2i+1 pair with complex element (i + M/2) mod M
+            double2 wv[NP], zv[NP];
 #pragma unroll
-            for (int j = 0; j < NA; ++j) {
-                const int n = (lt + j * T + M) & (N - 1);  // W == N: off = 0
-                const double s = ldsd[2 * lds_pad(n >> 1) + ((n & 1) ^ 1)] * p.inv_n;
-                acc[j] = acc[j] + wnd[j] * s;
+            for (int j = 0; j < NP; ++j) wv[j] = reinterpret_cast<const double2 *>(p.window)[(unsigned)(lt + j * T)];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) zv[j] = lds[lds_pad((lt + j * T + M / 2) & (M - 1))];
+            double2 cur[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const double2 old = j < NK ? tail[j] : make_double2(0.0, 0.0);
+                cur[j].x = old.x + wv[j].x * (zv[j].y * p.inv_n);
+                cur[j].y = old.y + wv[j].y * (zv[j].x * p.inv_n);
             }
             if (emit) {
-                double *yc = a.out + c * a.out_stride + f * p.H;
+                double2 *yc = reinterpret_cast<double2 *>(a.out + c * a.out_stride + f * p.H);
 #pragma unroll
-                for (int j = 0; j < NH; ++j) yc[(unsigned)(lt + j * T)] = acc[j];
+                for (int j = 0; j < NHP; ++j) yc[(unsigned)(lt + j * T)] = cur[j];
             }
 #pragma unroll
-            for (int j = 0; j < NA; ++j) acc[j] = (j + NH < NA) ? acc[j + NH] : 0.0;
+            for (int j = 0; j < NK; ++j) tail[j] = cur[j + NHP];
         } else {
             double *fo = a.out + row * p.W;
 #pragma unroll
-            for (int j = 0; j < NA; ++j) {
+            for (int j = 0; j < 16; ++j) {
                 const int i = lt + j * T;
                 const int n = (i + p.off + M) & (N - 1);
                 const double s = ldsd[2 * lds_pad(n >> 1) + ((n & 1) ^ 1)] * p.inv_n;
-                if (i < p.W) fo[i] = wnd[j] * s;
+                if (i < p.W) fo[(unsigned)i] = p.window[(unsigned)i] * s;
             }
         }
         __syncthreads();  // FFT buffer is rewritten by the next frame's spectrum
@@ -485,11 +491,12 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
             double *yc = a.out + c * a.out_stride;
             const long long start = a.F * p.H;
 #pragma unroll
-            for (int j = 0; j < NA - NH; ++j) {
-                const long long pos = start + tid + j * T;
-                if (pos < a.out_len) yc[pos] = acc[j];
+            for (int j = 0; j < NK; ++j) {
+                const long long pos = start + 2 * (tid + j * T);
+                if (pos < a.out_len) yc[pos] = tail[j].x;
+                if (pos + 1 < a.out_len) yc[pos + 1] = tail[j].y;
             }
-            for (long long pos = start + (NA - NH) * T + tid; pos < a.out_len; pos += T) yc[pos] = 0.0;
+            for (long long pos = start + 2 * NK * T + tid; pos < a.out_len; pos += T) yc[pos] = 0.0;
         }
     }
 }

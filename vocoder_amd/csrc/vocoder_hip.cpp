@@ -192,36 +192,36 @@ bool launch_analysis_fast(voc_ctx *c, const voc::AnaArgs &a, long long channels,
     return true;
 }
 
-// The register-resident overlap-add needs W == N (16 window samples per thread) and a hop that is
-// a multiple of the thread count.
-inline int fast_ola_nh(const voc_ctx *c)
+// The register-resident overlap-add needs W == N (eight sample pairs per thread), a hop that is a
+// multiple of twice the thread count, and 16-byte aligned output rows.  Returns H / 2T or 0.
+inline int fast_ola_nhp(const voc_ctx *c, const voc::SynArgs &a)
 {
     if (!fast_sizes(c) || c->W != c->N) return 0;
-    const int t = c->M / 8;
-    if (c->H % t != 0) return 0;
-    const int nh = c->H / t;
-    return (nh == 1 || nh == 2 || nh == 4 || nh == 8 || nh == 16) ? nh : 0;
+    const int t2 = 2 * (c->M / 8);
+    if (c->H % t2 != 0) return 0;
+    if (reinterpret_cast<uintptr_t>(a.out) % 16 != 0 || a.out_stride % 2 != 0) return 0;
+    const int nhp = c->H / t2;
+    return (nhp == 1 || nhp == 2 || nhp == 4 || nhp == 8) ? nhp : 0;
 }
 
 template <int L, bool OLA>
-void launch_synthesis_fast_nh(voc_ctx *c, const voc::SynArgs &a, unsigned grid, int nh, hipStream_t st)
+void launch_synthesis_fast_nh(voc_ctx *c, const voc::SynArgs &a, unsigned grid, int nhp, hipStream_t st)
 {
     const dim3 g(grid), b(voc::FastCfg<L>::T);
     const size_t lds = voc::FastCfg<L>::LDS_BYTES;
-    switch (nh) {
+    switch (nhp) {
     case 1: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 1>), g, b, lds, st, c->params, a); break;
     case 2: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 2>), g, b, lds, st, c->params, a); break;
     case 4: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 4>), g, b, lds, st, c->params, a); break;
-    case 8: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 8>), g, b, lds, st, c->params, a); break;
-    default: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 16>), g, b, lds, st, c->params, a); break;
+    default: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 8>), g, b, lds, st, c->params, a); break;
     }
 }
 
-// Specialised synthesis kernel (polar input): frames out, or overlap-add out when fast_ola_nh() != 0.
+// Specialised synthesis kernel (polar input): frames out, or overlap-add out when fast_ola_nhp() != 0.
 bool launch_synthesis_fast(voc_ctx *c, const voc::SynArgs &a, long long channels, bool ola, hipStream_t st)
 {
     if (!fast_sizes(c)) return false;
-    const int nh = ola ? fast_ola_nh(c) : 16;
+    const int nh = ola ? fast_ola_nhp(c, a) : 8;
     if (ola && nh == 0) return false;
     const long long grid = channels * a.tiles;
     if (grid <= 0) return true;
@@ -231,7 +231,7 @@ bool launch_synthesis_fast(voc_ctx *c, const voc::SynArgs &a, long long channels
 #define X(L)                                                                          \
     case L:                                                                           \
         if (ola) launch_synthesis_fast_nh<L, true>(c, a, (unsigned)grid, nh, st);     \
-        else hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, false, 16>), dim3((unsigned)grid), \
+        else hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, false, 8>), dim3((unsigned)grid), \
                                 dim3(voc::FastCfg<L>::T), voc::FastCfg<L>::LDS_BYTES, st, c->params, a); \
         break;
         VOC_FOR_EACH_FAST_LOG2M(X)
