@@ -239,22 +239,37 @@ VOC_DEV int frexp_exponent(double v)  // exponent e with |v| = m 2^e, 0.5 <= m <
 #endif
 }
 
+// One Horner step p*z + c with the coefficient read from a scalar register pair.  Written as an
+// instruction because the compiler otherwise selects the two-address multiply-add, which needs the
+// coefficient copied into a vector register first: one extra instruction per step and a vector
+// register pair per coefficient held across the loop.
+VOC_DEV double horner(double p, double z, double c)
+{
+#ifdef VOC_EMU
+    return fma(p, z, c);
+#else
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(z), "s"(c));
+    return r;
+#endif
+}
+
 // atan(t) = t + t z P(z), z = t^2, for |t| <= tan(pi/8): degree-10 minimax P (tools/gen_poly.py),
 // relative error 5e-18 before rounding.
 VOC_DEV double atan_poly(double t)
 {
     const double z = t * t;
     double p = -0x1.3b08efe0aa3adp-6;
-    p = fma(p, z, 0x1.41bf291d28cbdp-5);
-    p = fma(p, z, -0x1.a0bb5679f2cabp-5);
-    p = fma(p, z, 0x1.dfed1a54859f0p-5);
-    p = fma(p, z, -0x1.10fae2404e73fp-4);
-    p = fma(p, z, 0x1.3b126b14c8afbp-4);
-    p = fma(p, z, -0x1.745d0b879bfcfp-4);
-    p = fma(p, z, 0x1.c71c7187c0787p-4);
-    p = fma(p, z, -0x1.249249243a720p-3);
-    p = fma(p, z, 0x1.99999999993a8p-3);
-    p = fma(p, z, -0x1.5555555555555p-2);
+    p = horner(p, z, 0x1.41bf291d28cbdp-5);
+    p = horner(p, z, -0x1.a0bb5679f2cabp-5);
+    p = horner(p, z, 0x1.dfed1a54859f0p-5);
+    p = horner(p, z, -0x1.10fae2404e73fp-4);
+    p = horner(p, z, 0x1.3b126b14c8afbp-4);
+    p = horner(p, z, -0x1.745d0b879bfcfp-4);
+    p = horner(p, z, 0x1.c71c7187c0787p-4);
+    p = horner(p, z, -0x1.249249243a720p-3);
+    p = horner(p, z, 0x1.99999999993a8p-3);
+    p = horner(p, z, -0x1.5555555555555p-2);
     return fma(t * z, p, t);
 }
 
@@ -710,7 +725,22 @@ __global__ void phase_carry_kernel(Params p, const double *__restrict__ inc, lon
     const double *src = inc + c * F * ldk + k;
     long long next = (long long)tile_len - halo;  // frame count after which tile 1 starts
     int t = 1;
-    for (long long f = 0; f < F && t < tiles; ++f) {
+    long long f = 0;
+    // four loads in flight per thread; the additions stay in frame order
+    for (; f + 4 <= F && t < tiles; f += 4) {
+        const double d0 = src[f * ldk], d1 = src[(f + 1) * ldk], d2 = src[(f + 2) * ldk], d3 = src[(f + 3) * ldk];
+        const double dd[4] = {d0 * p.hop_d, d1 * p.hop_d, d2 * p.hop_d, d3 * p.hop_d};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ph = ph + dd[u];
+            if (f + u + 1 == next) {
+                if (t < tiles) carry[(c * tiles + t) * p.K + k] = ph;
+                ++t;
+                next += tile_len;
+            }
+        }
+    }
+    for (; f < F && t < tiles; ++f) {
         const double d = src[f * ldk] * p.hop_d;
         ph = ph + d;
         if (f + 1 == next) {

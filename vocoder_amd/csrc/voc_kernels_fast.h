@@ -20,6 +20,17 @@
 
 #include "voc_kernels.h"
 
+#ifndef VOC_SYN_FENCE
+#define VOC_SYN_FENCE 1
+#endif
+
+#ifndef VOC_POLAR_UNROLL
+#define VOC_POLAR_UNROLL 1  // bin pairs in flight in the analysis polar loop
+#endif
+
+#define VOC_PRAGMA_(x) _Pragma(#x)
+#define VOC_UNROLL(n) VOC_PRAGMA_(unroll n)
+
 #ifndef VOC_FAST_WAVES
 #define VOC_FAST_WAVES 3  // waves per SIMD the fast kernels are register-budgeted for
 #endif
@@ -311,7 +322,7 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
 
         const long long row = c * a.F + f;
         double *mrow = a.mag + row * a.ldk, *irow = a.inc + row * a.ldk;
-#pragma unroll 1
+VOC_UNROLL(VOC_POLAR_UNROLL)
         for (int m = 0; m < 4; ++m) {
             const unsigned pr = tid + m * T;
             const unsigned pe = pr == 0 ? M / 2 : pr;
@@ -429,7 +440,9 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
             merge_pair(A, B, split_tw(tw.s, m, pr == 0), Za, Zb);
             lds[lds_pad(pe)] = Za;
             lds[lds_pad(q)] = Zb;
+#if VOC_SYN_FENCE
             sched_fence();  // one bin pair at a time: interleaving all eight sincos chains overflows the register budget
+#endif
         }
         if (tid == 0) {  // DC and Nyquist: only the real parts enter the C2R transform
             double p0 = php[0], pm = php[M];
