@@ -140,7 +140,9 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, if collected
         if os.path.exists(tfile):
             try:
-                out["roofline"]["traffic"] = json.load(open(tfile)).get(names[dom])
+                t = json.load(open(tfile))
+                if t.get("streams_per_gpu") == args.streams:   # measured on this workload only
+                    out["roofline"]["traffic"] = t.get(names[dom])
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:

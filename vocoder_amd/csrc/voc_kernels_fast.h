@@ -20,6 +20,10 @@
 
 #include "voc_kernels.h"
 
+#ifndef VOC_WS_PREFETCH
+#define VOC_WS_PREFETCH 0  // fetch the window with the next frame's samples (aligned case)
+#endif
+
 #ifndef VOC_SYN_FENCE
 #define VOC_SYN_FENCE 1
 #endif
@@ -49,10 +53,13 @@ struct FastCfg {
 };
 
 // real-FFT split of the pair (Z[pe], Z[q]), q = M - pe:  X[pe] = E + W^pe O,  X[q] = conj(E - W^pe O)
-VOC_DEV void split_pair(double2 P, double2 Q, double2 tw, double2 &Xa, double2 &Xb)
+// with E = (P + conj Q)/2, O = (P - conj Q)/(2i).  Returned are 2 X[pe] and 2 X[q]: the halvings are
+// left out (exact powers of two: the phase is unchanged, the magnitude is exactly doubled and the
+// caller folds the 1/2 into its volume factor).
+VOC_DEV void split_pair_x2(double2 P, double2 Q, double2 tw, double2 &Xa, double2 &Xb)
 {
-    const double2 E = make_double2(0.5 * (P.x + Q.x), 0.5 * (P.y - Q.y));
-    const double2 O = make_double2(0.5 * (P.y + Q.y), 0.5 * (Q.x - P.x));
+    const double2 E = make_double2(P.x + Q.x, P.y - Q.y);
+    const double2 O = make_double2(P.y + Q.y, Q.x - P.x);
     const double2 U = cmul(tw, O);
     Xa = cadd(E, U);
     Xb = cconj(csub(E, U));
@@ -260,10 +267,16 @@ VOC_DEV void fft_after_first(double2 *lds, const FastTw<LOG2M> &t, int tid, doub
 
 // VEC2: W == N and every frame starts 16-byte aligned, so a thread's two adjacent samples and
 // window values are one 16-byte load each.
-template <int LOG2M, bool VEC2>
+// SLIDE > 0 (needs VEC2 and frames that start H = SLIDE * 2T samples apart in one signal): the
+// thread keeps its eight sample pairs of the current frame in registers, ordered by position in
+// the frame; the next frame is the same window moved by H, i.e. by SLIDE pair slots, so only the
+// SLIDE newest pairs are loaded.  Every input sample is then fetched once per workgroup instead of
+// N/H times (those re-reads were missing L2: measured 3.2x the unique input bytes).
+template <int LOG2M, bool VEC2, int SLIDE>
 __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fast_kernel(Params p, AnaArgs a)
 {
     constexpr int M = FastCfg<LOG2M>::M, T = FastCfg<LOG2M>::T;
+    constexpr int NEW = SLIDE > 0 ? SLIDE : 8;  // pair slots loaded per frame
     VOC_SMEM(double2, lds);
     double *php = reinterpret_cast<double *>(lds + FastCfg<LOG2M>::LDS_CPLX);  // previous raw phase, K bins
     const int tid = threadIdx.x;
@@ -283,41 +296,54 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
     FastTw<LOG2M> tw;  // frame-invariant twiddle bases of this thread
     fast_tw_init<LOG2M>(p, tid, tw);
 
-    // samples and window of frame f, even/odd packed, rewound: v[n] = padded[(n + N/2) mod N]
-    double2 xs[8];
-    auto load_frame = [&](long long f) {
-        const double *fr = xc + f * a.frame_stride;
+    // Slot u holds the sample pair at frame positions 2 tid + 2 u T (+1).  The first FFT pass reads
+    // the frame rewound (v[n] = padded[(n + N/2) mod N]) and even/odd packed: its element
+    // tid + j T is slot (j + 4) mod 8.
+    double2 xs[8], xn[NEW], ws[8];
+    auto sample_pair = [&](const double *fr, int u) -> double2 {
+        const unsigned i0 = (unsigned)(2 * (tid + u * T));  // unsigned: SGPR base + 32-bit lane offset
+        if (VEC2) return *reinterpret_cast<const double2 *>(fr + i0);
+        const int j0 = (int)i0 - p.hd, j1 = j0 + 1;
+        return make_double2((j0 >= 0 && j0 < p.W) ? fr[j0] : 0.0, (j1 >= 0 && j1 < p.W) ? fr[j1] : 0.0);
+    };
+    auto load_window = [&]() {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const unsigned i0 = (unsigned)(2 * (tid + j * T) + M) & (unsigned)(2 * M - 1);  // unsigned: SGPR base + 32-bit lane offset
+        for (int u = 0; u < 8; ++u) {
+            const unsigned i0 = (unsigned)(2 * (tid + u * T));
             if (VEC2) {
-                xs[j] = *reinterpret_cast<const double2 *>(fr + i0);
+                ws[u] = *reinterpret_cast<const double2 *>(p.window + i0);
             } else {
                 const int j0 = (int)i0 - p.hd, j1 = j0 + 1;
-                xs[j] = make_double2((j0 >= 0 && j0 < p.W) ? fr[j0] : 0.0, (j1 >= 0 && j1 < p.W) ? fr[j1] : 0.0);
+                ws[u] = make_double2((j0 >= 0 && j0 < p.W) ? p.window[j0] : 0.0, (j1 >= 0 && j1 < p.W) ? p.window[j1] : 0.0);
             }
         }
     };
-    auto window_at = [&](int j) -> double2 {
-        const unsigned i0 = (unsigned)(2 * (tid + j * T) + M) & (unsigned)(2 * M - 1);
-        if (VEC2) return *reinterpret_cast<const double2 *>(p.window + i0);
-        const int j0 = (int)i0 - p.hd, j1 = j0 + 1;
-        return make_double2((j0 >= 0 && j0 < p.W) ? p.window[j0] : 0.0, (j1 >= 0 && j1 < p.W) ? p.window[j1] : 0.0);
-    };
 
+    const double half_vol = 0.5 * a.vol;  // exact; undoes the doubling of split_pair_x2
     const long long fs = f0 > 0 ? f0 - 1 : f0;  // one frame early to recover its raw phase
-    load_frame(fs);
+    {
+        const double *fr = xc + fs * a.frame_stride;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xs[u] = sample_pair(fr, u);
+        load_window();
+    }
     for (long long f = fs; f < f1; ++f) {
         const bool emit = f >= f0;
+        if (!(VEC2 && VOC_WS_PREFETCH) && f > fs) load_window();  // predicated loads: not worth the registers of a prefetch
         double2 v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const double2 w = window_at(j);
-            v[j] = make_double2(w.x * xs[j].x, w.y * xs[j].y);
+            const int u = (j + 4) & 7;
+            v[j] = make_double2(ws[u].x * xs[u].x, ws[u].y * xs[u].y);
         }
         dft<8>(v);
         fft_after_first<LOG2M>(lds, tw, tid, v, [&]() {
-            if (f + 1 < f1) load_frame(f + 1);
+            if (f + 1 < f1) {  // the pairs of the next frame that are not already in registers, and the window again
+                const double *fr = xc + (f + 1) * a.frame_stride;
+#pragma unroll
+                for (int i = 0; i < NEW; ++i) xn[i] = sample_pair(fr, 8 - NEW + i);
+                if (VEC2 && VOC_WS_PREFETCH) load_window();
+            }
         });
 
         const long long row = c * a.F + f;
@@ -328,14 +354,14 @@ VOC_UNROLL(VOC_POLAR_UNROLL)
             const unsigned pe = pr == 0 ? M / 2 : pr;
             const unsigned q = M - pe;
             double2 Xa, Xb;
-            split_pair(lds[lds_pad(pe)], lds[lds_pad(q)], split_tw(tw.s, m, pr == 0), Xa, Xb);
+            split_pair_x2(lds[lds_pad(pe)], lds[lds_pad(q)], split_tw(tw.s, m, pr == 0), Xa, Xb);
             const double pa = php[pe], pb = php[q];
             double ma, mb, pha, phb;
             hs_polar(Xa.x, Xa.y, ma, pha);
             hs_polar(Xb.x, Xb.y, mb, phb);
             if (emit) {
-                mrow[pe] = ma * a.vol;
-                mrow[q] = mb * a.vol;
+                mrow[pe] = ma * half_vol;
+                mrow[q] = mb * half_vol;
                 irow[pe] = phase_inc(p, pe, pha - pa);
                 irow[q] = phase_inc(p, q, phb - pb);
             }
@@ -355,6 +381,11 @@ VOC_UNROLL(VOC_POLAR_UNROLL)
             php[0] = ph0;
             php[M] = phm;
         }
+        // slide the sample window by one hop
+#pragma unroll
+        for (int u = 0; u < 8 - NEW; ++u) xs[u] = xs[u + NEW];
+#pragma unroll
+        for (int i = 0; i < NEW; ++i) xs[8 - NEW + i] = xn[i];
         // the next frame's first LDS write sits behind the first barrier of fft_after_first
     }
 

@@ -174,17 +174,26 @@ bool launch_analysis_fast(voc_ctx *c, const voc::AnaArgs &a, long long channels,
     if (grid > 0x7fffffffLL) throw HipFail{hipErrorInvalidValue, "analysis grid too large"};
     const bool vec2 = c->W == c->N && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0) && a.chan_stride % 2 == 0 &&
                       a.frame_stride % 2 == 0;
+    // frames cut from one signal, hop a multiple of 2T: the sample window slides in registers
+    const int t2 = 2 * (c->M / 8);
+    int slide = 0;
+    if (vec2 && a.frame_stride == c->H && c->H % t2 == 0) {
+        const int sl = c->H / t2;
+        if (sl == 1 || sl == 2 || sl == 4) slide = sl;
+    }
     LaunchTimer timer(c, KIND_ANALYSIS, st);
+    const dim3 g((unsigned)grid);
     switch (c->log2m) {
-#define X(L)                                                                                                   \
-    case L:                                                                                                    \
-        if (vec2)                                                                                              \
-            hipLaunchKernelGGL((voc::analysis_fast_kernel<L, true>), dim3((unsigned)grid),                     \
-                               dim3(voc::FastCfg<L>::T), voc::FastCfg<L>::LDS_BYTES, st, c->params, a);        \
-        else                                                                                                   \
-            hipLaunchKernelGGL((voc::analysis_fast_kernel<L, false>), dim3((unsigned)grid),                    \
-                               dim3(voc::FastCfg<L>::T), voc::FastCfg<L>::LDS_BYTES, st, c->params, a);        \
-        break;
+#define X(L)                                                                                                        \
+    case L: {                                                                                                       \
+        const dim3 b(voc::FastCfg<L>::T);                                                                           \
+        const size_t lds = voc::FastCfg<L>::LDS_BYTES;                                                              \
+        if (!vec2) hipLaunchKernelGGL((voc::analysis_fast_kernel<L, false, 0>), g, b, lds, st, c->params, a);       \
+        else if (slide == 1) hipLaunchKernelGGL((voc::analysis_fast_kernel<L, true, 1>), g, b, lds, st, c->params, a); \
+        else if (slide == 2) hipLaunchKernelGGL((voc::analysis_fast_kernel<L, true, 2>), g, b, lds, st, c->params, a); \
+        else if (slide == 4) hipLaunchKernelGGL((voc::analysis_fast_kernel<L, true, 4>), g, b, lds, st, c->params, a); \
+        else hipLaunchKernelGGL((voc::analysis_fast_kernel<L, true, 0>), g, b, lds, st, c->params, a);              \
+    } break;
         VOC_FOR_EACH_FAST_LOG2M(X)
 #undef X
     }
