@@ -161,6 +161,29 @@ int32_t voc_roundtrip_dev(voc_ctx *ctx, const double *x, int64_t x_stride, int64
                           double *leftover, int64_t leftover_stride, void *workspace, int64_t workspace_bytes,
                           void *stream);
 
+/* ---- the two halves of the fused path, device pointers ---------------------------------------
+ * For callers that put something between analysis and synthesis (a frequency-domain filter,
+ * Conduit.hs:47; a change of frame rate, Conduit/Filter.hs:122-136) or that cut a long signal
+ * into time segments.
+ * voc_analysis_signal_dev   genFramesOfE W H (Frames.hs:26-38) .| analysisStage (Vocoder.hs:149-154),
+ *                           times volumeCoeff (Conduit.hs:34-35) when volume_fix != 0: frame j of
+ *                           channel c is read in place from x[c][j*H .. j*H+W).
+ * voc_synthesis_signal_dev  synthesisStage (Vocoder.hs:177-182) .| sumFramesE (Frames.hs:41-58):
+ *                           y[c][0 .. y_len) receives the overlap-add of the F frames, zeros
+ *                           past sample (F-1)*H+W; y_len >= (F-1)*H+W.
+ * voc_phase_advance_dev     the phase half of synthesisStage alone: phase_io <- the accumulated
+ *                           phase after the F frames (Vocoder.hs:190), nothing else computed.
+ *   mag, ph_inc [C][F][ldk], ldk >= K (row pitch in doubles); phase_io [C][K] in/out.
+ */
+int32_t voc_analysis_signal_dev(voc_ctx *ctx, const double *x, int64_t x_stride, int64_t nframes, int64_t channels,
+                                double *phase_io, double *mag, double *ph_inc, int64_t ldk, int32_t volume_fix,
+                                void *stream);
+int32_t voc_synthesis_signal_dev(voc_ctx *ctx, const double *mag, const double *ph_inc, int64_t ldk, int64_t nframes,
+                                 int64_t channels, double *phase_io, double *y, int64_t y_stride, int64_t y_len,
+                                 void *stream);
+int32_t voc_phase_advance_dev(voc_ctx *ctx, const double *ph_inc, int64_t ldk, int64_t nframes, int64_t channels,
+                              double *phase_io, void *stream);
+
 /* ---- measurement hook (no counterpart in the reference) ------------------------------------------
  * With profiling on, every kernel launch made through the context is bracketed by HIP events
  * on its launch stream.  voc_profile_read waits for them, adds the elapsed milliseconds and

@@ -1,0 +1,115 @@
+"""GPU: the two halves of the fused path as separate entry points, and the time-sharded round trip
+(ranks run one after the other in this process; the exchanges are the same tensor operations the
+distributed driver performs)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers import TOL_L2  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _hann(n):
+    return 0.5 * (1 - np.cos(2 * np.pi * np.arange(n) / n))
+
+
+def _signal(c, length, seed=11):
+    rng = np.random.default_rng(seed)
+    t = np.arange(length)
+    return np.stack([0.5 * np.sin(2 * np.pi * (0.01 + 0.003 * i) * t + i) for i in range(c)]) + \
+        1e-2 * rng.uniform(-1, 1, (c, length))
+
+
+def _wrap_err(a, b):
+    d = np.abs(a - b) % (2 * np.pi)
+    return np.minimum(d, 2 * np.pi - d).max()
+
+
+@pytest.mark.parametrize("n,w,hop", [(4096, 4096, 1024), (256, 200, 64), (16384, 16384, 4096)])
+def test_split_entry_points_equal_fused_roundtrip(gpu_lib, n, w, hop):
+    import ctypes as C
+    import torch
+    from vocoder_amd import vocoder as V, conduit as Cd
+    par = V.VocoderParams(n, hop, _hann(w), lib=gpu_lib)
+    c, frames = 3, 21
+    length = w + hop * (frames - 1) + 5
+    x = torch.from_numpy(_signal(c, length)).cuda()
+    olen = Cd.ola_length(par, frames, hop)
+    y1 = torch.empty((c, olen), dtype=torch.float64, device="cuda")
+    a1 = torch.zeros((c, par.K), dtype=torch.float64, device="cuda")
+    s1 = torch.zeros_like(a1)
+    Cd.process_dev(par, x, y1, a1, s1)
+
+    ldk = (par.K + 1) & ~1
+    mag = torch.empty((c, frames, ldk), dtype=torch.float64, device="cuda")
+    inc = torch.empty_like(mag)
+    a2, s2, adv = torch.zeros_like(a1), torch.zeros_like(a1), torch.zeros_like(a1)
+    y2 = torch.empty_like(y1)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    par._call("voc_analysis_signal_dev", p(x), x.stride(0), frames, c, p(a2), p(mag), p(inc), ldk, 1, st)
+    par._call("voc_phase_advance_dev", p(inc), ldk, frames, c, p(adv), st)
+    par._call("voc_synthesis_signal_dev", p(mag), p(inc), ldk, frames, c, p(s2), p(y2), y2.stride(0), olen, st)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2) and torch.equal(a1, a2) and torch.equal(s1, s2)
+    assert torch.equal(adv, s2)          # the chain alone ends on the same bits as the chain inside synthesis
+
+
+def test_split_entry_points_reject_bad_sizes(gpu_lib):
+    import ctypes as C
+    import torch
+    from vocoder_amd import vocoder as V
+    par = V.VocoderParams(64, 16, _hann(64), lib=gpu_lib)
+    t = torch.zeros(4096, dtype=torch.float64, device="cuda")
+    p = C.c_void_p(t.data_ptr())
+    d = gpu_lib.dll
+    assert d.voc_analysis_signal_dev(par.handle, p, 64 + 16, 3, 1, p, p, p, 34, 1, None) == -5     # row too short
+    assert d.voc_analysis_signal_dev(par.handle, p, 200, 3, 1, p, p, p, 32, 1, None) == -5         # ldk < K
+    assert d.voc_synthesis_signal_dev(par.handle, p, p, 34, 3, 1, p, p, 200, 64 + 31, None) == -5  # y_len too short
+    assert d.voc_phase_advance_dev(par.handle, None, 34, 3, 1, p, None) == -1
+    assert d.voc_analysis_signal_dev(par.handle, p, 200, 0, 1, p, p, p, 34, 1, None) == 0          # no frames: no-op
+
+
+@pytest.mark.parametrize("n,hop,world,frames_per_rank", [(4096, 1024, 4, 12), (1024, 256, 3, 9)])
+def test_time_sharded_matches_sequential(gpu_lib, orc, n, hop, world, frames_per_rank):
+    import torch
+    from vocoder_amd import vocoder as V, conduit as Cd, timeshard as T
+    win = _hann(n)
+    par = V.VocoderParams(n, hop, win, lib=gpu_lib)
+    c = 4
+    length = n + hop * (frames_per_rank * world + 2) + 9
+    x = _signal(c, length)
+    xt = torch.from_numpy(x).cuda()
+    plans = [T.plan(par, length, world, r) for r in range(world)]
+    ana = [T.analyse(par, sp, xt[:, sp.in_lo:sp.in_hi].contiguous()) for sp in plans]
+    totals = [T.local_advance(par, inc) for _, inc, _ in ana]
+    outs = [T.synthesise(par, sp, m, i, T.start_phase(totals, sp.rank)) for sp, (m, i, _) in zip(plans, ana)]
+    ys = []
+    for r, (sp, (y, _)) in enumerate(zip(plans, outs)):
+        if r > 0:
+            pv = plans[r - 1]
+            T.add_incoming_tail(y, outs[r - 1][0][:, pv.out_hi - pv.out_lo:].clone())
+        ys.append(y[:, :sp.out_hi - sp.out_lo])
+    y = torch.cat(ys, dim=1)
+
+    # against the unsharded run on the same GPU
+    f = Cd.num_frames(par, length)
+    y_seq = torch.empty((c, Cd.ola_length(par, f, hop)), dtype=torch.float64, device="cuda")
+    aph = torch.zeros((c, par.K), dtype=torch.float64, device="cuda")
+    sph = torch.zeros_like(aph)
+    Cd.process_dev(par, xt, y_seq, aph, sph)
+    torch.cuda.synchronize()
+    assert y.shape == y_seq.shape
+    rel = (torch.linalg.norm(y - y_seq) / torch.linalg.norm(y_seq)).item()
+    assert rel <= 1e-12, rel                                # differs only by re-association at rank boundaries
+    assert torch.equal(ana[-1][2], aph)                     # raw phase of the last frame: no exchange involved
+    assert _wrap_err(outs[-1][1].cpu().numpy(), sph.cpu().numpy()) <= 1e-9
+
+    # and against the sequential oracle
+    ref = orc.roundtrip(n, hop, win, x[0], hop, np.zeros(par.K), np.zeros(par.K))
+    yy = y[0].cpu().numpy()
+    assert np.linalg.norm(yy - ref["y"]) / np.linalg.norm(ref["y"]) <= TOL_L2

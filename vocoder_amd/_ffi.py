@@ -45,6 +45,9 @@ SIGNATURES = {
     "voc_sum_frames": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i64]),
     "voc_roundtrip": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64]),
     "voc_roundtrip_workspace_bytes": (_i64, [_vp, _i64, _i64]),
+    "voc_analysis_signal_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "voc_synthesis_signal_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _vp]),
+    "voc_phase_advance_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "voc_profile_enable": (_i32, [_vp, _i32]),
     "voc_profile_read": (_i32, [_vp, _vp, _vp]),
     "voc_roundtrip_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),

@@ -751,6 +751,30 @@ __global__ void phase_carry_kernel(Params p, const double *__restrict__ inc, lon
     }
 }
 
+// The synthesis phase chain alone: phase_io <- fold (ph + ph_inc * H) over the F frames, in frame
+// order (synthesisStep, Vocoder.hs:190).  Used where only the phase a run of frames ends on is
+// needed (time-sharded runs exchange it between segments).
+__global__ void phase_advance_kernel(Params p, const double *__restrict__ inc, long long ldk, long long F,
+                                     double *__restrict__ phase_io, long long channels)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= channels * p.K) return;
+    const long long c = g / p.K;
+    const int k = (int)(g % p.K);
+    double ph = phase_io[g];
+    const double *src = inc + c * F * ldk + k;
+    long long f = 0;
+    for (; f + 4 <= F; f += 4) {
+        const double d0 = src[f * ldk], d1 = src[(f + 1) * ldk], d2 = src[(f + 2) * ldk], d3 = src[(f + 3) * ldk];
+        ph = ph + d0 * p.hop_d;
+        ph = ph + d1 * p.hop_d;
+        ph = ph + d2 * p.hop_d;
+        ph = ph + d3 * p.hop_d;
+    }
+    for (; f < F; ++f) ph = ph + src[f * ldk] * p.hop_d;
+    phase_io[g] = ph;
+}
+
 // ------------------------------------------------------------------ step-level, framing, overlap-add
 
 // analysisStep over B independent frames (Vocoder.hs:158-163)

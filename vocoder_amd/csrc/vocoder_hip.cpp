@@ -385,14 +385,100 @@ void synthesis_stage_dev(voc_ctx *c, double *phase_io, const double *mag, const 
     if (!launch_synthesis_fast(c, a, C, false, st)) launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_FRAMES>(c, a, C, st);
 }
 
+// genFramesOfE + analysisStage (+ volumeFix) on signal rows: frame j of a channel is read in place
+// at sample j*H (Frames.hs:34-35).
+void analysis_signal_dev(voc_ctx *c, const double *x, long long x_stride, long long F, long long C, double *phase_io,
+                         double *mag, double *inc, long long ldk, bool volume_fix, hipStream_t st)
+{
+    if (C <= 0 || F <= 0) return;
+    ensure_ws(c, (size_t)C * c->K * sizeof(double));
+    double *pin = static_cast<double *>(c->ws);
+    HIPCHK(hipMemcpyAsync(pin, phase_io, (size_t)C * c->K * sizeof(double), hipMemcpyDeviceToDevice, st));
+    voc::AnaArgs a{};
+    a.x = x;
+    a.chan_stride = x_stride;
+    a.frame_stride = c->H;
+    a.phase_in = pin;
+    a.phase_out = phase_io;
+    a.mag = mag;
+    a.inc = inc;
+    a.ldk = ldk;
+    a.F = F;
+    a.tile_len = analysis_tile_len(c, C, F);
+    a.tiles = (int)((F + a.tile_len - 1) / a.tile_len);
+    a.vol = volume_fix ? c->vol : 1.0;
+    if (!launch_analysis_fast(c, a, C, st)) launch_analysis<false, false>(c, a, C, st);
+}
+
+constexpr size_t kLdsLimit = 160 * 1024;
+
+// synthesisStage + sumFramesE: y rows receive y_len samples each (zeros past the last frame).
+void synthesis_signal_dev(voc_ctx *c, const double *mag, const double *inc, long long ldk, long long F, long long C,
+                          double *phase_io, double *y, long long y_stride, long long y_len, hipStream_t st)
+{
+    if (C <= 0 || F <= 0) return;
+    const bool fused = lds_bytes(c, true) <= kLdsLimit;
+    const int halo = fused ? (c->W + c->H - 1) / c->H - 1 : 0;
+    int tile_len, tiles;
+    synthesis_tiling(c, C, F, halo, &tile_len, &tiles);
+    const size_t nph = (size_t)C * c->K;
+    const size_t ncarry = tiles > 1 ? (size_t)C * tiles * c->K : 0;
+    const size_t nframes = fused ? 0 : (size_t)C * F * c->W;
+    ensure_ws(c, (nph + ncarry + nframes) * sizeof(double));
+    double *pin = static_cast<double *>(c->ws);
+    double *carry = pin + nph;
+    double *frames = carry + ncarry;
+    HIPCHK(hipMemcpyAsync(pin, phase_io, nph * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (tiles > 1) {
+        const long long chains = C * c->K;
+        LaunchTimer timer(c, KIND_CARRY, st);
+        hipLaunchKernelGGL(voc::phase_carry_kernel, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, c->params,
+                           inc, ldk, F, pin, carry, tile_len, tiles, halo, C);
+        HIPCHK(hipGetLastError());
+    }
+    voc::SynArgs s{};
+    s.mag = mag;
+    s.inc = inc;
+    s.ldk = ldk;
+    s.phase_in = pin;
+    s.carry = carry;
+    s.phase_out = phase_io;
+    s.out = y;
+    s.out_stride = y_stride;
+    s.out_len = y_len;
+    s.F = F;
+    s.tile_len = tile_len;
+    s.tiles = tiles;
+    s.halo = halo;
+    if (fused) {
+        if (!launch_synthesis_fast(c, s, C, true, st)) launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_OLA>(c, s, C, st);
+    } else {
+        s.out = frames;
+        if (!launch_synthesis_fast(c, s, C, false, st)) launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_FRAMES>(c, s, C, st);
+        const long long total = C * y_len;
+        hipLaunchKernelGGL(voc::sum_frames_kernel, dim3(ew_grid(total)), dim3(256), 0, st, frames, F, c->W, c->H, y,
+                           y_stride, y_len, total);
+        HIPCHK(hipGetLastError());
+    }
+}
+
+void phase_advance_dev(voc_ctx *c, const double *inc, long long ldk, long long F, long long C, double *phase_io,
+                       hipStream_t st)
+{
+    if (C <= 0 || F <= 0) return;
+    const long long chains = C * c->K;
+    LaunchTimer timer(c, KIND_CARRY, st);
+    hipLaunchKernelGGL(voc::phase_advance_kernel, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, c->params, inc,
+                       ldk, F, phase_io, C);
+    HIPCHK(hipGetLastError());
+}
+
 struct RtPlan {
     long long F, out_len, ldk;
     int ana_tile, ana_tiles, syn_tile, syn_tiles, halo;
     bool fused_ola;            // overlap-add ring fits in LDS beside the FFT buffer
     size_t per_channel_bytes;  // STFT + carry + two phase snapshots (+ frames when not fused)
 };
-
-constexpr size_t kLdsLimit = 160 * 1024;
 
 RtPlan roundtrip_plan(const voc_ctx *c, long long len, long long group, long long chunk)
 {
@@ -901,6 +987,50 @@ VOC_EXPORT int32_t voc_roundtrip_dev(voc_ctx *c, const double *x, int64_t x_stri
         Locked lk(c);
         roundtrip_dev(c, x, x_stride, len, C, chunk, y, y_stride, ana_phase_io, syn_phase_io, leftover,
                       leftover_stride, workspace, workspace_bytes, (hipStream_t)stream);
+        return VOC_OK;
+    });
+}
+
+VOC_EXPORT int32_t voc_analysis_signal_dev(voc_ctx *c, const double *x, int64_t x_stride, int64_t F, int64_t C,
+                                           double *phase_io, double *mag, double *ph_inc, int64_t ldk,
+                                           int32_t volume_fix, void *stream)
+{
+    if (!c || C < 0 || F < 0) return VOC_ERR_INVALID;
+    if (C == 0 || F == 0) return VOC_OK;
+    if (!x || !phase_io || !mag || !ph_inc) return VOC_ERR_INVALID;
+    if (ldk < c->K || x_stride < (F - 1) * (int64_t)c->H + c->W) return VOC_ERR_SIZE;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c);
+        analysis_signal_dev(c, x, x_stride, F, C, phase_io, mag, ph_inc, ldk, volume_fix != 0, (hipStream_t)stream);
+        return VOC_OK;
+    });
+}
+
+VOC_EXPORT int32_t voc_synthesis_signal_dev(voc_ctx *c, const double *mag, const double *ph_inc, int64_t ldk, int64_t F,
+                                            int64_t C, double *phase_io, double *y, int64_t y_stride, int64_t y_len,
+                                            void *stream)
+{
+    if (!c || C < 0 || F < 0) return VOC_ERR_INVALID;
+    if (C == 0 || F == 0) return VOC_OK;
+    if (!mag || !ph_inc || !phase_io || !y) return VOC_ERR_INVALID;
+    if (ldk < c->K || y_len < (F - 1) * (int64_t)c->H + c->W || y_stride < y_len) return VOC_ERR_SIZE;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c);
+        synthesis_signal_dev(c, mag, ph_inc, ldk, F, C, phase_io, y, y_stride, y_len, (hipStream_t)stream);
+        return VOC_OK;
+    });
+}
+
+VOC_EXPORT int32_t voc_phase_advance_dev(voc_ctx *c, const double *ph_inc, int64_t ldk, int64_t F, int64_t C,
+                                         double *phase_io, void *stream)
+{
+    if (!c || C < 0 || F < 0) return VOC_ERR_INVALID;
+    if (C == 0 || F == 0) return VOC_OK;
+    if (!ph_inc || !phase_io) return VOC_ERR_INVALID;
+    if (ldk < c->K) return VOC_ERR_SIZE;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c);
+        phase_advance_dev(c, ph_inc, ldk, F, C, phase_io, (hipStream_t)stream);
         return VOC_OK;
     });
 }

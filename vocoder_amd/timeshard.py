@@ -1,0 +1,203 @@
+"""Time-sharded round trip: every rank owns a run of consecutive frames of every channel.
+
+The reference processes a signal strictly in order; what it carries from one stretch of a signal
+to the next is the triple of vocoder-audio/src/Vocoder/Audio.hs:31-33 — samples not yet framed,
+the analysis phase and the synthesis phase.  Each of the three has a counterpart here:
+
+* samples: rank g reads its frames' samples plus, for g > 0, the H samples before them, i.e. the
+  frame that precedes its first one.  analysisStep keeps only the raw phase of the previous frame
+  (Vocoder.hs:158-163), so analysing that one extra frame recovers the carried phase locally;
+* synthesis phase: the chain ph <- ph + H * ph_inc (Vocoder.hs:190) is a running sum.  Each rank
+  folds its own frames from zero, the per-rank totals (C*K doubles) are all-gathered, and every
+  rank adds the totals of the ranks below it to the initial phase, in rank order, to obtain the
+  value its chain starts from.  This is the one step that re-associates the reference's
+  additions: accumulated phases agree with the sequential fold to a few ulp of their magnitude,
+  not bit for bit;
+* overlap-add: the last W-H output samples of rank g receive contributions from rank g+1's first
+  frames.  Rank g sends that tail to rank g+1, which adds its own partial sums to it (older frames
+  first, as sumFramesE folds them, Frames.hs:41-58).
+
+The per-rank work runs through the C ABI (voc_analysis_signal_dev, voc_phase_advance_dev,
+voc_synthesis_signal_dev); torch is used for the buffers and for the two exchanges.  Tensors may
+live on a GPU (RCCL) or, with the host build of the kernels used by the CPU tests, in host memory
+(gloo).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+from .distributed import shard_range
+
+__all__ = ["SegmentPlan", "plan", "analyse", "local_advance", "start_phase", "synthesise", "add_incoming_tail",
+           "process"]
+
+
+@dataclass(frozen=True)
+class SegmentPlan:
+    rank: int
+    world: int
+    frames_total: int
+    f_lo: int          # first frame owned
+    f_hi: int          # one past the last frame owned
+    has_prev: bool     # the input slice starts one hop early (frame f_lo - 1 is analysed for its phase)
+    in_lo: int         # input samples needed: [in_lo, in_hi)
+    in_hi: int
+    out_lo: int        # output samples owned: [out_lo, out_hi)
+    out_hi: int
+    local_len: int     # samples the local overlap-add produces, starting at out_lo
+    tail: int          # samples handed to the next rank (0 on the last rank)
+
+    @property
+    def frames(self) -> int:
+        return self.f_hi - self.f_lo
+
+
+def plan(par, length: int, world: int, rank: int, chunk: int | None = None) -> SegmentPlan:
+    """Frame and sample ranges of `rank` for a signal of `length` samples per channel."""
+    W, H = par.W, par.H
+    chunk = H if chunk is None else chunk
+    F = par.lib.dll.voc_num_frames(par.handle, int(length))
+    f_lo, f_hi = shard_range(F, world, rank)
+    tail = max(W - H, 0)
+    if world > 1:
+        smallest = F // world
+        if smallest < 1 or smallest * H < tail:
+            raise ValueError(f"{F} frames over {world} ranks: segments shorter than the overlap of {tail} samples")
+    last = rank == world - 1
+    has_prev = rank > 0
+    in_lo = f_lo * H - (H if has_prev else 0)
+    in_hi = (f_hi - 1) * H + W
+    out_lo = f_lo * H
+    if last:
+        out_hi = par.lib.dll.voc_ola_length(par.handle, F, int(chunk))
+        local_len = out_hi - out_lo
+        tail_out = 0
+    else:
+        out_hi = f_hi * H
+        local_len = max((f_hi - f_lo) * H, (f_hi - f_lo - 1) * H + W)
+        tail_out = local_len - (out_hi - out_lo)
+    return SegmentPlan(rank, world, F, f_lo, f_hi, has_prev, in_lo, in_hi, out_lo, out_hi, local_len, tail_out)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream) if t.is_cuda else None
+
+
+def analyse(par, sp: SegmentPlan, x_seg, ana_phase=None, volume_fix: bool = True):
+    """Analysis of the rank's frames.  x_seg (C, >= in_hi - in_lo) holds samples in_lo.. of every
+    channel.  ana_phase (C, K) is the phase before frame 0 and is used by rank 0 only.
+    Returns (mag, ph_inc) of shape (C, frames, ldk) and the raw phase of the rank's last frame."""
+    import torch
+
+    assert x_seg.dtype == torch.float64 and x_seg.stride(-1) == 1
+    c = x_seg.shape[0]
+    ldk = (par.K + 1) & ~1
+    mag = torch.empty((c, sp.frames, ldk), dtype=torch.float64, device=x_seg.device)
+    inc = torch.empty_like(mag)
+    ph = torch.zeros((c, par.K), dtype=torch.float64, device=x_seg.device)
+    st = _stream(x_seg)
+    if sp.has_prev:
+        # one frame ahead of the segment, for its raw phase only (its magnitudes are dropped)
+        scratch = torch.empty((2, c, 1, ldk), dtype=torch.float64, device=x_seg.device)
+        par._call("voc_analysis_signal_dev", _ptr(x_seg), x_seg.stride(0), 1, c, _ptr(ph), _ptr(scratch[0]),
+                  _ptr(scratch[1]), ldk, 0, st)
+        first = x_seg[:, par.H:]
+    else:
+        if ana_phase is not None:
+            ph.copy_(ana_phase)
+        first = x_seg
+    par._call("voc_analysis_signal_dev", _ptr(first), x_seg.stride(0), sp.frames, c, _ptr(ph), _ptr(mag), _ptr(inc),
+              ldk, 1 if volume_fix else 0, st)
+    return mag, inc, ph
+
+
+def local_advance(par, inc):
+    """Total phase advance of the rank's frames: the synthesis chain folded from zero."""
+    import torch
+
+    c, f, ldk = inc.shape
+    total = torch.zeros((c, par.K), dtype=torch.float64, device=inc.device)
+    par._call("voc_phase_advance_dev", _ptr(inc), ldk, f, c, _ptr(total), _stream(inc))
+    return total
+
+
+def start_phase(totals, rank: int, syn_phase=None):
+    """Phase the chain of `rank` starts from: the initial phase plus the totals of ranks 0..rank-1,
+    added in rank order (the same sequence on every rank)."""
+    import torch
+
+    start = torch.zeros_like(totals[0]) if syn_phase is None else syn_phase.clone()
+    for r in range(rank):
+        start = start + totals[r]
+    return start
+
+
+def synthesise(par, sp: SegmentPlan, mag, inc, start):
+    """Synthesis and local overlap-add of the rank's frames.  Returns (y_local (C, local_len),
+    phase after the rank's last frame)."""
+    import torch
+
+    c, f, ldk = mag.shape
+    y = torch.empty((c, sp.local_len), dtype=torch.float64, device=mag.device)
+    ph = start.clone()
+    par._call("voc_synthesis_signal_dev", _ptr(mag), _ptr(inc), ldk, f, c, _ptr(ph), _ptr(y), y.stride(0),
+              sp.local_len, _stream(mag))
+    return y, ph
+
+
+def add_incoming_tail(y_local, tail):
+    """Adds the previous rank's tail under the first samples of this rank's output: the older
+    frames' partial sums come first, then this rank's (Frames.hs:52-58 folds oldest first)."""
+    n = tail.shape[1]
+    if n:
+        y_local[:, :n] = tail + y_local[:, :n]
+    return y_local
+
+
+def process(par, x_seg, length: int, chunk: int | None = None, ana_phase=None, syn_phase=None, group=None):
+    """Round trip of one time segment under torch.distributed (identity filter).
+
+    Every rank passes its slice x_seg (C, in_hi - in_lo) of the signal of `length` samples per
+    channel (`plan` gives the ranges) and receives the output samples [out_lo, out_hi) it owns.
+    Returns (y_owned, (ana_phase', syn_phase')) — the phases after the last frame of the whole
+    signal, identical on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    sp = plan(par, length, world, rank, chunk)
+    mag, inc, aph = analyse(par, sp, x_seg, ana_phase)
+    total = local_advance(par, inc)
+    if world > 1:
+        totals = [torch.empty_like(total) for _ in range(world)]
+        dist.all_gather(totals, total, group=group)
+    else:
+        totals = [total]
+    y, sph = synthesise(par, sp, mag, inc, start_phase(totals, rank, syn_phase))
+    if world > 1:
+        reqs = []
+        tail_in = None
+        if sp.tail:
+            send = y[:, sp.out_hi - sp.out_lo:].contiguous()
+            reqs.append(dist.isend(send, dist.get_global_rank(group, rank + 1) if group else rank + 1, group=group))
+        if rank > 0:
+            prev = plan(par, length, world, rank - 1, chunk)
+            if prev.tail:
+                tail_in = torch.empty((y.shape[0], prev.tail), dtype=torch.float64, device=y.device)
+                reqs.append(dist.irecv(tail_in, dist.get_global_rank(group, rank - 1) if group else rank - 1,
+                                       group=group))
+        for r in reqs:
+            r.wait()
+        if tail_in is not None:
+            add_incoming_tail(y, tail_in)
+        last = dist.get_global_rank(group, world - 1) if group else world - 1
+        dist.broadcast(aph, last, group=group)
+        dist.broadcast(sph, last, group=group)
+    return y[:, :sp.out_hi - sp.out_lo], (aph, sph)
