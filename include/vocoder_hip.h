@@ -184,6 +184,72 @@ int32_t voc_synthesis_signal_dev(voc_ctx *ctx, const double *mag, const double *
 int32_t voc_phase_advance_dev(voc_ctx *ctx, const double *ph_inc, int64_t ldk, int64_t nframes, int64_t channels,
                               double *phase_io, void *stream);
 
+/* ---- frequency-domain filters (vocoder/src/Vocoder/Filter.hs) -----------------------------------
+ * A voc_filter is a chain in composeFilters order (Filter.hs:54-55; vocoder-file folds its
+ * command-line filters the same way, vocoder-audio/example/VocoderFile.hs:72); an empty chain
+ * is idFilter (Filter.hs:62-63).  freq_step is the reference's FreqStep, sample rate / frame
+ * length (vocoder-audio/src/Vocoder/Audio.hs:49).  voc_filter_append(kind, params, nparams):
+ *   VOC_FILTER_AMPLIFY                 k           amplify                 Filter.hs:80-81
+ *   VOC_FILTER_LOWPASS_BRICKWALL       t           lowpassBrickwall        Filter.hs:84-85
+ *   VOC_FILTER_HIGHPASS_BRICKWALL      t           highpassBrickwall       Filter.hs:88-89
+ *   VOC_FILTER_BANDPASS_BRICKWALL      t,u         bandpassBrickwall       Filter.hs:92-93
+ *   VOC_FILTER_BANDSTOP_BRICKWALL      t,u         bandstopBrickwall       Filter.hs:96-97
+ *   VOC_FILTER_LOWPASS_BUTTERWORTH     n,t         lowpassButterworth      Filter.hs:103-104
+ *   VOC_FILTER_HIGHPASS_BUTTERWORTH    n,t         highpassButterworth     Filter.hs:107-108
+ *   VOC_FILTER_BANDPASS_BUTTERWORTH    n,t,u       bandpassButterworth     Filter.hs:111-112
+ *   VOC_FILTER_BANDSTOP_BUTTERWORTH    n,t,u       bandstopButterworth     Filter.hs:115-116
+ *   VOC_FILTER_GAIN_TABLE              g[0..K)     linearAmplitudeFilter f with g[k] = f (step*k),
+ *                                                  evaluated by the caller    Filter.hs:76-77
+ *   VOC_FILTER_PITCH_SHIFT_INTERPOLATE n > 0       pitchShiftInterpolate   Filter.hs:118-129
+ *   VOC_FILTER_CONVOLUTION             ker[0..len) convolutionFilter       Filter.hs:132-141
+ *   VOC_FILTER_ENVELOPE                ksize       envelopeFilter          Filter.hs:144-152
+ *   VOC_FILTER_RANDOM_PHASE            seed < 2^53 randomPhaseFilter       Filter.hs:156-157
+ * The reference draws randomPhaseFilter's increments from the unseeded global generator, so
+ * its values are not reproducible; here they are Philox-4x32-10 words keyed by the seed with
+ * counter (bin, row, position in the chain), row = channel * nframes + frame.
+ * voc_filter_apply[_dev] runs the chain in place on mag / ph_inc ([C][F][K] host arrays, or
+ * device arrays with row pitch ldk).  At most 12 operations per chain (VOC_ERR_SIZE beyond).
+ * addFilters (Filter.hs:58-59) is not provided: run two chains on copies and voc_add_frames.
+ */
+typedef struct voc_filter voc_filter;
+enum {
+    VOC_FILTER_AMPLIFY = 0,
+    VOC_FILTER_LOWPASS_BRICKWALL = 1,
+    VOC_FILTER_HIGHPASS_BRICKWALL = 2,
+    VOC_FILTER_BANDPASS_BRICKWALL = 3,
+    VOC_FILTER_BANDSTOP_BRICKWALL = 4,
+    VOC_FILTER_LOWPASS_BUTTERWORTH = 5,
+    VOC_FILTER_HIGHPASS_BUTTERWORTH = 6,
+    VOC_FILTER_BANDPASS_BUTTERWORTH = 7,
+    VOC_FILTER_BANDSTOP_BUTTERWORTH = 8,
+    VOC_FILTER_GAIN_TABLE = 9,
+    VOC_FILTER_PITCH_SHIFT_INTERPOLATE = 10,
+    VOC_FILTER_CONVOLUTION = 11,
+    VOC_FILTER_ENVELOPE = 12,
+    VOC_FILTER_RANDOM_PHASE = 13
+};
+int32_t voc_filter_create(voc_ctx *ctx, double freq_step, voc_filter **out);
+int32_t voc_filter_destroy(voc_filter *f);
+int32_t voc_filter_length(const voc_filter *f);
+int32_t voc_filter_append(voc_filter *f, int32_t kind, const double *params, int32_t nparams);
+int32_t voc_filter_apply(voc_filter *f, double *mag, double *ph_inc, int64_t nframes, int64_t channels);
+int32_t voc_filter_apply_dev(voc_filter *f, double *mag, double *ph_inc, int64_t ldk, int64_t nframes,
+                             int64_t channels, void *stream);
+
+/* ---- playSpeed (vocoder-conduit/src/Vocoder/Conduit/Filter.hs:122-136) --------------------------
+ * playSpeed coeff replicates or drops STFT frames: after i input frames floor(i * coeff) frames
+ * have been emitted, each emission repeating the newest input frame.  coeff = num / den exactly
+ * (the reference takes a Rational: toRational of the command-line double, VocoderFile.hs:119).
+ * voc_play_speed_frames  number of frames emitted for nframes_in input frames
+ * voc_play_speed_map     src[j] = input frame that output frame j repeats (host array)
+ * voc_gather_frames_dev  mag_out/inc_out[c][j][:] = mag_in/inc_in[c][src[j]][:], src on the device
+ */
+int64_t voc_play_speed_frames(int64_t num, int64_t den, int64_t nframes_in);
+int32_t voc_play_speed_map(int64_t num, int64_t den, int64_t nframes_in, int64_t *src, int64_t capacity);
+int32_t voc_gather_frames_dev(voc_ctx *ctx, const double *mag_in, const double *inc_in, int64_t ldk, int64_t nframes_in,
+                              const int64_t *src_dev, int64_t nframes_out, double *mag_out, double *inc_out,
+                              int64_t channels, void *stream);
+
 /* ---- measurement hook (no counterpart in the reference) ------------------------------------------
  * With profiling on, every kernel launch made through the context is bracketed by HIP events
  * on its launch stream.  voc_profile_read waits for them, adds the elapsed milliseconds and

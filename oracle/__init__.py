@@ -28,7 +28,7 @@ WINDOW_KINDS = {
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (see oracle/Makefile)."""
-    src = [os.path.join(_HERE, f) for f in ("vocoder_oracle.c", "frames_generic.inc", "Makefile")]
+    src = [os.path.join(_HERE, f) for f in ("vocoder_oracle.c", "frames_generic.inc", "filters_oracle.c", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src)
     if force or stale:
@@ -59,6 +59,16 @@ def lib():
         _lib.orc_phase.argtypes = [C.c_double, C.c_double]
         _lib.orc_make_window.argtypes = [C.c_int, C.c_double, C.c_int, _dp]
         _lib.orc_num_frames.restype = C.c_int64
+        _lib.orc_filter_linear.argtypes = [C.c_int, _dp, C.c_double, C.c_int, _dp]
+        _lib.orc_interpolate.argtypes = [C.c_double, _dp, C.c_int, _dp]
+        _lib.orc_filter_pitch_shift.argtypes = [C.c_double, C.c_int, _dp, _dp]
+        _lib.orc_convolution.argtypes = [_dp, C.c_int, _dp, C.c_int, _dp]
+        _lib.orc_filter_convolution.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp]
+        _lib.orc_envelope_kernel.argtypes = [C.c_int, _dp]
+        _lib.orc_envelope.argtypes = [C.c_int, _dp, C.c_int, _dp]
+        _lib.orc_filter_envelope.argtypes = [C.c_int, C.c_int, _dp, _dp]
+        _lib.orc_play_speed.restype = C.c_int64
+        _lib.orc_play_speed.argtypes = [C.c_int64, C.c_int64, C.c_int64, _ip, C.c_int64]
         _lib.orc_num_frames.argtypes = [C.c_int64, C.c_int, C.c_int]
         _lib.orc_ola_length.restype = C.c_int64
         _lib.orc_ola_length.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int64]
@@ -318,3 +328,76 @@ def sum_frames_s(hop: int, ticks, out_lens, dtype=np.float64):
         res.append(out[pos: pos + n].copy())
         pos += int(n)
     return res
+
+
+# --------------------------------------------------------------------------- filters (Vocoder.Filter)
+LINEAR_FILTERS = {
+    "amplify": 0, "lowpass_brickwall": 1, "highpass_brickwall": 2, "bandpass_brickwall": 3,
+    "bandstop_brickwall": 4, "lowpass_butterworth": 5, "highpass_butterworth": 6,
+    "bandpass_butterworth": 7, "bandstop_butterworth": 8,
+}
+
+
+def apply_filter(step: float, chain, mag, ph_inc):
+    """Runs a chain [(name, params...), ...] in composeFilters order (Filter.hs:54-55) on every
+    frame of mag / ph_inc (.., K).  Names: the LINEAR_FILTERS, "gain_table" (g,), "pitch_shift"
+    (n,), "convolution" (ker,), "envelope" (ksize,).  Returns new (mag, ph_inc)."""
+    mag, inc = _f64(mag).copy(), _f64(ph_inc).copy()
+    k = mag.shape[-1]
+    m2, i2 = mag.reshape(-1, k), inc.reshape(-1, k)
+    L = lib()
+    for name, *prm in chain:
+        for r in range(m2.shape[0]):
+            mr, ir = m2[r], i2[r]
+            if name in LINEAR_FILTERS:
+                q = _f64(prm)
+                L.orc_filter_linear(LINEAR_FILTERS[name], _d(q), float(step), k, _d(mr))
+            elif name == "gain_table":
+                mr *= _f64(prm[0])                      # linearAmplitudeFilter with a tabulated f
+            elif name == "pitch_shift":
+                L.orc_filter_pitch_shift(float(prm[0]), k, _d(mr), _d(ir))
+            elif name == "convolution":
+                ker = _f64(prm[0])
+                L.orc_filter_convolution(_d(ker), ker.size, k, _d(mr), _d(ir))
+            elif name == "envelope":
+                L.orc_filter_envelope(int(prm[0]), k, _d(mr), _d(ir))
+            else:
+                raise ValueError(name)
+    return mag, inc
+
+
+def interpolate(n: float, v) -> np.ndarray:
+    v = _f64(v)
+    out = np.empty_like(v)
+    lib().orc_interpolate(float(n), _d(v), v.size, _d(out))
+    return out
+
+
+def convolution(ker, mag) -> np.ndarray:
+    ker, mag = _f64(ker), _f64(mag)
+    out = np.empty_like(mag)
+    lib().orc_convolution(_d(ker), ker.size, _d(mag), mag.size, _d(out))
+    return out
+
+
+def envelope_kernel(ksize: int) -> np.ndarray:
+    out = np.empty(ksize)
+    lib().orc_envelope_kernel(int(ksize), _d(out))
+    return out
+
+
+def envelope(ksize: int, mag) -> np.ndarray:
+    mag = _f64(mag)
+    out = np.empty_like(mag)
+    lib().orc_envelope(int(ksize), _d(mag), mag.size, _d(out))
+    return out
+
+
+def play_speed(num: int, den: int, nframes_in: int) -> np.ndarray:
+    """Input frame index repeated by each frame playSpeed (num/den) emits (Conduit/Filter.hs:122-136)."""
+    cap = nframes_in * num // den + 2
+    src = np.empty(cap, dtype=np.int64)
+    n = lib().orc_play_speed(int(num), int(den), int(nframes_in), src.ctypes.data_as(_ip), cap)
+    if n < 0:
+        raise RuntimeError("play_speed: capacity")
+    return src[:n].copy()

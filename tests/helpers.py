@@ -124,3 +124,55 @@ def check_roundtrip(lib, orc, n, w, h, length, c, rng, ana_tile=0, syn_tile=0, c
         return y
     finally:
         set_tiles()
+
+
+# ---------------------------------------------------------------------------------- filters
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox-4x32-10 on numpy uint32 arrays (written from the published round function)."""
+    import numpy as np
+    c = [np.asarray(v, dtype=np.uint64) for v in np.broadcast_arrays(c0, c1, c2, c3)]
+    k0, k1 = int(k0), int(k1)
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[0]
+        p1 = np.uint64(0xCD9E8D57) * c[2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        c = [hi1 ^ c[1] ^ np.uint64(k0), lo1, hi0 ^ c[3] ^ np.uint64(k1), lo0]
+        k0 = (k0 + 0x9E3779B9) & 0xFFFFFFFF
+        k1 = (k1 + 0xBB67AE85) & 0xFFFFFFFF
+    return c
+
+
+def random_phase_expected(seed, rows, k, position):
+    """ph_inc the library's random-phase operation writes: 53 bits of Philox words 0,1 scaled to
+    [0, 2 pi); counter (bin, row low, row high, position in the chain), key = seed."""
+    import numpy as np
+    bins = np.arange(k, dtype=np.uint64)[None, :]
+    row = np.arange(rows, dtype=np.uint64)[:, None]
+    r = philox4x32_10(bins, row & np.uint64(0xFFFFFFFF), row >> np.uint64(32), np.uint64(position),
+                      seed & 0xFFFFFFFF, seed >> 32)
+    bits = ((r[0] << np.uint64(32)) | r[1]) >> np.uint64(11)
+    return (bits.astype(np.float64) * 2.0 ** -53) * (2 * np.pi)
+
+
+def oracle_filtered(orc, n, hop, window, x, step, chain, speed=None, chunk=None):
+    """The reference pipeline with a filter on one channel, from oracle pieces: analysis and
+    volumeFix (orc.roundtrip's STFT), the filter chain, playSpeed, synthesisStage, sumFramesE."""
+    import numpy as np
+    w = len(window)
+    k = n // 2 + 1
+    chunk = hop if chunk is None else chunk
+    rt = orc.roundtrip(n, hop, window, x, chunk, want_stft=True)
+    mag, inc = orc.apply_filter(step, chain, rt["mag"], rt["ph_inc"]) if chain else (rt["mag"], rt["ph_inc"])
+    if speed is not None:
+        src = orc.play_speed(speed.numerator, speed.denominator, mag.shape[0])
+        mag, inc = mag[src], inc[src]
+    f = mag.shape[0]
+    y = np.zeros(orc.ola_length(f, w, hop, chunk))
+    if f:
+        sph, frames = orc.synthesis_stage(n, hop, window, np.zeros(k), mag, inc)
+        for j in range(f):
+            y[j * hop:j * hop + w] = y[j * hop:j * hop + w] + frames[j]
+    else:
+        sph = np.zeros(k)
+    return dict(y=y, mag=mag, ph_inc=inc, syn_phase=sph, ana_phase=rt["ana_phase"])

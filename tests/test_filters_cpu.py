@@ -1,0 +1,166 @@
+"""Filter chains and playSpeed through the C ABI on CPU (host-emulated build of the kernel
+source): index logic, chain order, error behaviour.  Checker: the filter oracle."""
+import ctypes as C
+import os
+import sys
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers import TOL_L2, oracle_filtered, random_phase_expected  # noqa: E402
+
+
+def _hann(n):
+    return 0.5 * (1 - np.cos(2 * np.pi * np.arange(n) / n))
+
+
+@pytest.fixture
+def par(emu_lib):
+    from vocoder_amd import vocoder as V
+    return V.VocoderParams(128, 32, _hann(128), lib=emu_lib)
+
+
+def _stft(par, c=2, f=5, seed=0):
+    rng = np.random.default_rng(seed)
+    return rng.uniform(0, 1, (c, f, par.K)), rng.uniform(-1, 1, (c, f, par.K))
+
+
+CHAINS = [
+    [("amplify", 0.3)],
+    [("lowpass_brickwall", 3000.0)],
+    [("highpass_brickwall", 3000.0)],
+    [("bandpass_brickwall", 1000.0, 5000.0)],
+    [("bandstop_brickwall", 1000.0, 5000.0)],
+    [("lowpass_butterworth", 4.0, 2000.0)],
+    [("highpass_butterworth", 4.0, 2000.0)],
+    [("bandpass_butterworth", 2.0, 1000.0, 4000.0)],
+    [("bandstop_butterworth", 2.0, 1000.0, 4000.0)],
+    [("pitch_shift", 2.0)],
+    [("pitch_shift", 0.77)],
+    [("convolution", (0.25, 0.5, 1.0, 0.5))],
+    [("envelope", 3)],
+    [("envelope", 9)],
+    [("pitch_shift", 2.0), ("lowpass_brickwall", 1000.0)],
+    [("lowpass_butterworth", 2.0, 3000.0), ("pitch_shift", 1.5), ("amplify", 2.0), ("envelope", 5), ("amplify", 0.5)],
+]
+
+
+def _describe(chain):
+    from vocoder_amd import filter as Fl
+    f = Fl.id_filter()
+    for name, *prm in chain:
+        fn = {"pitch_shift": Fl.pitch_shift_interpolate, "convolution": lambda k: Fl.convolution_filter(k),
+              "envelope": Fl.envelope_filter}.get(name) or getattr(Fl, name)
+        f = Fl.compose_filters(f, fn(*prm))
+    return f
+
+
+@pytest.mark.parametrize("chain", CHAINS, ids=lambda c: "+".join(s[0] for s in c))
+def test_chain_matches_oracle(par, orc, chain):
+    step = 48000.0 / par.N
+    mag, inc = _stft(par)
+    m, i = _describe(chain).bind(par, step).apply(mag, inc)
+    chain_o = [(n, np.array(p[0])) if n == "convolution" else (n, *p) for n, *p in chain]
+    mo, io = orc.apply_filter(step, chain_o, mag, inc)
+    has_env = any(s[0] == "envelope" for s in chain)
+    if has_env:   # log / exp come from different math libraries
+        assert np.allclose(m, mo, rtol=1e-12, atol=1e-15)
+    else:
+        assert np.array_equal(m, mo)
+    assert np.array_equal(i, io)
+
+
+def test_gain_table_and_function(par, orc):
+    from vocoder_amd import filter as Fl
+    step = 375.0
+    mag, inc = _stft(par, seed=4)
+    fn = lambda x: 1.0 / (1.0 + x / 1000.0)
+    m, i = Fl.linear_amplitude_filter(fn).bind(par, step).apply(mag, inc)
+    g = np.array([fn(step * k) for k in range(par.K)])
+    assert np.array_equal(m, mag * g) and np.array_equal(i, inc)
+
+
+def test_identity_and_long_chain(par):
+    from vocoder_amd import filter as Fl
+    mag, inc = _stft(par, seed=5)
+    m, i = Fl.id_filter().bind(par, 1.0).apply(mag, inc)
+    assert np.array_equal(m, mag) and np.array_equal(i, inc)
+    f = Fl.id_filter()
+    for _ in range(15):                                   # more than one device chain holds: split in two
+        f = f >> Fl.amplify(1.25)
+    b = f.bind(par, 1.0)
+    assert [k for k, _ in b.parts] == ["chain", "chain"]
+    m, _ = b.apply(mag, inc)
+    ref = mag.copy()
+    for _ in range(15):
+        ref = ref * 1.25
+    assert np.array_equal(m, ref)
+
+
+def test_random_phase_is_the_documented_philox_stream(par):
+    from vocoder_amd import filter as Fl
+    mag, inc = _stft(par, c=2, f=3, seed=6)
+    seed = 0x1234_5678_9ABC
+    m, i = (Fl.amplify(1.0) >> Fl.random_phase_filter(seed)).bind(par, 1.0).apply(mag, inc)
+    assert np.array_equal(m, mag)
+    exp = random_phase_expected(seed, 6, par.K, position=1).reshape(2, 3, par.K)
+    assert np.array_equal(i, exp)
+    assert i.min() >= 0 and i.max() < 2 * np.pi and abs(i.mean() - np.pi) < 0.2
+
+
+def test_append_errors(par, emu_lib):
+    d = emu_lib.dll
+    h = C.c_void_p()
+    assert d.voc_filter_create(par.handle, 375.0, C.byref(h)) == 0
+    q = (C.c_double * 3)(1.0, 2.0, 3.0)
+    assert d.voc_filter_append(h, 1, q, 2) == -1          # lowpassBrickwall takes one parameter
+    assert d.voc_filter_append(h, 99, q, 1) == -1
+    assert d.voc_filter_append(h, 9, q, 3) == -5          # gain table must have K entries
+    q[0] = 0.0
+    assert d.voc_filter_append(h, 10, q, 1) == -1         # pitch coefficient must be positive
+    assert d.voc_filter_append(h, 12, q, 1) == -1         # envelope size >= 1
+    assert d.voc_filter_length(h) == 0
+    q[0] = 2.0
+    for _ in range(12):
+        assert d.voc_filter_append(h, 0, q, 1) == 0
+    assert d.voc_filter_append(h, 0, q, 1) == -5          # chain full
+    assert d.voc_filter_destroy(h) == 0
+    assert d.voc_filter_apply_dev(None, None, None, 0, 0, 0, None) == -1
+
+
+@pytest.mark.parametrize("coeff", [Fraction(1), Fraction(2), Fraction(1, 2), Fraction(3, 2), Fraction(0.3), Fraction(1.3)])
+def test_play_speed_map_matches_state_machine(par, orc, coeff):
+    from vocoder_amd import filter as Fl
+    for f_in in (0, 1, 9, 100):
+        assert np.array_equal(Fl.play_speed_map(par, coeff, f_in), orc.play_speed(coeff.numerator, coeff.denominator, f_in))
+    assert par.lib.dll.voc_play_speed_map(1, 0, 4, None, 0) == -1
+    buf = np.empty(2, dtype=np.int64)
+    assert par.lib.dll.voc_play_speed_map(2, 1, 4, buf.ctypes.data_as(C.c_void_p), 2) == -5
+
+
+@pytest.mark.parametrize("chain,speed", [
+    ([("pitch_shift", 2.0), ("lowpass_brickwall", 3000.0)], None),
+    ([("envelope", 8)], None),
+    ([], Fraction(2)),
+    ([("amplify", 0.5)], Fraction(2, 3)),
+])
+def test_filtered_pipeline_matches_oracle(par, orc, chain, speed):
+    import torch
+    from vocoder_amd import conduit as Cd, filter as Fl
+    step = 48000.0 / par.N
+    rng = np.random.default_rng(9)
+    length = 128 + 32 * 14 + 5
+    t = np.arange(length)
+    x = np.stack([0.5 * np.sin(2 * np.pi * 0.03 * (c + 1) * t) + 0.01 * rng.uniform(-1, 1, length) for c in range(2)])
+    f = _describe(chain)
+    if speed is not None:
+        f = f >> Fl.play_speed(speed)
+    y, aph, sph = Cd.process_filter_dev(par, f.bind(par, step), torch.from_numpy(x))
+    for c in range(2):
+        ref = oracle_filtered(orc, par.N, par.H, _hann(128), x[c], step,
+                              [(n, *p) for n, *p in chain], speed)
+        assert y.shape[1] == ref["y"].size
+        err = np.linalg.norm(y[c].numpy() - ref["y"]) / max(np.linalg.norm(ref["y"]), 1e-300)
+        assert err <= TOL_L2, err

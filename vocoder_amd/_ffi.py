@@ -48,6 +48,15 @@ SIGNATURES = {
     "voc_analysis_signal_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
     "voc_synthesis_signal_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _vp]),
     "voc_phase_advance_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "voc_filter_create": (_i32, [_vp, C.c_double, C.POINTER(_vp)]),
+    "voc_filter_destroy": (_i32, [_vp]),
+    "voc_filter_length": (_i32, [_vp]),
+    "voc_filter_append": (_i32, [_vp, _i32, _vp, _i32]),
+    "voc_filter_apply": (_i32, [_vp, _vp, _vp, _i64, _i64]),
+    "voc_filter_apply_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "voc_play_speed_frames": (_i64, [_i64, _i64, _i64]),
+    "voc_play_speed_map": (_i32, [_i64, _i64, _i64, _vp, _i64]),
+    "voc_gather_frames_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
     "voc_profile_enable": (_i32, [_vp, _i32]),
     "voc_profile_read": (_i32, [_vp, _vp, _vp]),
     "voc_roundtrip_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),

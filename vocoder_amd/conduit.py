@@ -16,7 +16,7 @@ import numpy as np
 from .vocoder import VocoderParams, _f64, _p, zero_phase
 
 __all__ = ["num_frames", "leftover_length", "ola_length", "frames_of_e", "sum_frames_e", "process_with",
-           "process", "process_dev", "roundtrip_workspace_bytes"]
+           "process", "process_dev", "roundtrip_workspace_bytes", "process_filter_dev"]
 
 
 def num_frames(par: VocoderParams, length: int) -> int:
@@ -114,3 +114,40 @@ def process_dev(par: VocoderParams, x, y, ana_phase, syn_phase, length: int | No
     par._call("voc_roundtrip_dev", C.c_void_p(x.data_ptr()), x.stride(0), length, c, chunk,
               C.c_void_p(y.data_ptr()), y.stride(0), C.c_void_p(ana_phase.data_ptr()),
               C.c_void_p(syn_phase.data_ptr()), lp, ls, wp, wb, C.c_void_p(st))
+
+
+def process_filter_dev(par: VocoderParams, filt, x, length: int | None = None, chunk: int | None = None,
+                       ana_phase=None, syn_phase=None):
+    """`processWith` with a frequency-domain filter (Conduit.hs:46-47): framing .| analysis .|
+    volumeFix .| filter .| synthesis .| overlap-add, all in device memory.
+
+    filt: a `vocoder_amd.filter.BoundFilter` (or None for idFilter).  x (C, >= length) is a torch
+    float64 tensor on the GPU (or in host memory with the host build of the kernels used by the
+    CPU tests); phases (C, K) are updated in place when given.  Returns (y, ana_phase, syn_phase)
+    with y (C, ola_length(frames after the filter))."""
+    import torch
+
+    assert x.dtype == torch.float64 and x.stride(-1) == 1
+    c = x.shape[0]
+    length = x.shape[1] if length is None else length
+    chunk = par.H if chunk is None else chunk
+    dev = x.device
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if x.is_cuda else None
+    aph = torch.zeros((c, par.K), dtype=torch.float64, device=dev) if ana_phase is None else ana_phase
+    sph = torch.zeros((c, par.K), dtype=torch.float64, device=dev) if syn_phase is None else syn_phase
+    f = num_frames(par, length)
+    ldk = (par.K + 1) & ~1
+    mag = torch.empty((c, f, ldk), dtype=torch.float64, device=dev)
+    inc = torch.empty_like(mag)
+    if f:
+        par._call("voc_analysis_signal_dev", C.c_void_p(x.data_ptr()), x.stride(0), f, c, C.c_void_p(aph.data_ptr()),
+                  C.c_void_p(mag.data_ptr()), C.c_void_p(inc.data_ptr()), ldk, 1, st)
+    if filt is not None:
+        mag, inc = filt.apply_dev(mag, inc)
+    fo = mag.shape[1]
+    n = ola_length(par, fo, chunk)
+    y = torch.empty((c, n), dtype=torch.float64, device=dev)
+    if fo:
+        par._call("voc_synthesis_signal_dev", C.c_void_p(mag.data_ptr()), C.c_void_p(inc.data_ptr()), ldk, fo, c,
+                  C.c_void_p(sph.data_ptr()), C.c_void_p(y.data_ptr()), y.stride(0), n, st)
+    return y, aph, sph

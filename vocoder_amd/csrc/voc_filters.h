@@ -1,0 +1,162 @@
+// voc_filters.h -- frequency-domain filters applied to the STFT where it rests in HBM between the
+// analysis and the synthesis kernel (vocoder/src/Vocoder/Filter.hs), and the frame-axis gather
+// of playSpeed (vocoder-conduit/src/Vocoder/Conduit/Filter.hs:122-136).
+//
+// A filter chain (composeFilters, Filter.hs:54-55) is a short program of row operations.  One
+// workgroup takes one STFT row (one frame of one channel: K moduli and K phase increments),
+// keeps it in LDS, runs every operation of the chain on it in order and writes it back, so a
+// chain of any length reads and writes the STFT once.  Rows too long for LDS (K > 5000) use a
+// per-workgroup scratch area in global memory through the same code.
+//
+// Rounding follows the reference operation by operation (compiled with -ffp-contract=off):
+// gains are one multiply per filter in chain order, interpolation is (1-k)*v[i] + k*v[i+1] with
+// both products rounded, the convolution divides every term by the kernel sum inside the
+// left-to-right sum.
+#pragma once
+
+namespace voc {
+
+enum { FOP_GAIN = 0, FOP_PITCH = 1, FOP_CONV = 2, FOP_ENVELOPE = 3, FOP_RANDOM_PHASE = 4 };
+constexpr int kMaxFilterOps = 12;
+
+struct FilterOp {
+    int kind;
+    int len;              // kernel length (convolution, envelope)
+    double a;             // pitch coefficient n | kernel sum s
+    const double *table;  // gain per bin [K] | kernel [len]
+    unsigned long long seed;
+};
+
+struct FilterProg {
+    int n;
+    FilterOp op[kMaxFilterOps];
+};
+
+// interpolate n v at index x (Filter.hs:118-125)
+VOC_DEV double interpolate_at(const double *v, int K, double n, int x)
+{
+    const double xp = n * (double)x;
+    if (!(xp < (double)(K - 1))) return 0.0;  // i + 1 >= length v
+    const int i = (int)floor(xp);
+    const double k = xp - (double)i;
+    const double lo = (1.0 - k) * v[i];
+    const double hi = k * v[i + 1];
+    return lo + hi;
+}
+
+// convolution ker mag at bin k (Filter.hs:132-137): gmag is mag with h zeros on both sides
+VOC_DEV double convolve_at(const double *mag, int K, const double *ker, int len, double s, int k)
+{
+    const int h = len / 2;
+    double acc = 0.0;
+    for (int i = 0; i < len; ++i) {
+        const int j = i + k - h;
+        const double g = (j >= 0 && j < K) ? mag[j] : 0.0;
+        acc = acc + (ker[i] * g) / s;
+    }
+    return acc;
+}
+
+VOC_DEV unsigned mulhi32(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+
+// Philox-4x32-10 (Salmon et al., SC'11): counter (c0..c3), key (k0, k1) -> first two output words
+VOC_DEV void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned *r0,
+                           unsigned *r1)
+{
+    for (int round = 0; round < 10; ++round) {
+        const unsigned hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    *r0 = c0;
+    *r1 = c1;
+}
+
+__global__ __launch_bounds__(256) void filter_rows_kernel(Params p, FilterProg prog, double *__restrict__ mag,
+                                                          double *__restrict__ inc, long long ldk, long long rows,
+                                                          double *gscratch)
+{
+    VOC_SMEM(double, lds);
+    const int K = p.K;
+    const int Kp = (K + 1) & ~1;
+    double *buf = gscratch ? gscratch + (size_t)blockIdx.x * 4 * Kp : lds;
+    double *cm = buf, *ci = buf + Kp, *tm = buf + 2 * Kp, *ti = buf + 3 * Kp;
+    const int tid = threadIdx.x, T = blockDim.x;
+    const double ee = 5.9604644775390625e-08;  // 2**(-24), Filter.hs:147
+    for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+        double *mrow = mag + row * ldk, *irow = inc + row * ldk;
+        for (int k = tid; k < K; k += T) {
+            cm[k] = mrow[k];
+            ci[k] = irow[k];
+        }
+        __syncthreads();
+        for (int o = 0; o < prog.n; ++o) {
+            const FilterOp op = prog.op[o];
+            switch (op.kind) {
+            case FOP_GAIN:  // linearAmplitudeFilter (Filter.hs:76-77): mag * gain, phase increments kept
+                for (int k = tid; k < K; k += T) cm[k] = cm[k] * op.table[k];
+                break;
+            case FOP_PITCH: {  // pitchShiftInterpolate (Filter.hs:128-129)
+                for (int k = tid; k < K; k += T) {
+                    tm[k] = interpolate_at(cm, K, op.a, k);
+                    ti[k] = interpolate_at(ci, K, op.a, k) / op.a;
+                }
+                double *t = cm; cm = tm; tm = t;
+                t = ci; ci = ti; ti = t;
+            } break;
+            case FOP_CONV: {  // convolutionFilter (Filter.hs:140-141): amplitudeFilter0 zeroes ph_inc
+                for (int k = tid; k < K; k += T) {
+                    tm[k] = convolve_at(cm, K, op.table, op.len, op.a, k);
+                    ci[k] = 0.0;
+                }
+                double *t = cm; cm = tm; tm = t;
+            } break;
+            case FOP_ENVELOPE: {  // envelopeFilter (Filter.hs:144-152)
+                for (int k = tid; k < K; k += T) cm[k] = log(cm[k] + ee);
+                __syncthreads();
+                for (int k = tid; k < K; k += T) {
+                    tm[k] = exp(convolve_at(cm, K, op.table, op.len, op.a, k)) + (-ee);
+                    ci[k] = 0.0;
+                }
+                double *t = cm; cm = tm; tm = t;
+            } break;
+            case FOP_RANDOM_PHASE:  // randomPhaseFilter (Filter.hs:156-157): ph_inc uniform on [0, 2 pi)
+                for (int k = tid; k < K; k += T) {
+                    unsigned r0, r1;
+                    philox4x32_10((unsigned)k, (unsigned)row, (unsigned)((unsigned long long)row >> 32), (unsigned)o,
+                                  (unsigned)op.seed, (unsigned)(op.seed >> 32), &r0, &r1);
+                    const unsigned long long bits = (((unsigned long long)r0 << 32) | r1) >> 11;
+                    ci[k] = ((double)bits * 1.1102230246251565e-16) * kTwoPi;  // 53 random bits * 2^-53 * 2 pi
+                }
+                break;
+            default: break;
+            }
+            __syncthreads();
+        }
+        for (int k = tid; k < K; k += T) {
+            mrow[k] = cm[k];
+            irow[k] = ci[k];
+        }
+        __syncthreads();
+    }
+}
+
+// playSpeed: output frame j of every channel is input frame src[j] (Conduit/Filter.hs:122-136).
+__global__ void gather_frames_kernel(const double *__restrict__ mag_in, const double *__restrict__ inc_in, long long ldk,
+                                     long long F_in, const long long *__restrict__ src, long long F_out,
+                                     double *__restrict__ mag_out, double *__restrict__ inc_out, long long total)
+{
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const long long k = g % ldk;
+        const long long row = g / ldk;
+        const long long j = row % F_out, c = row / F_out;
+        const long long from = (c * F_in + src[j]) * ldk + k;
+        mag_out[g] = mag_in[from];
+        inc_out[g] = inc_in[from];
+    }
+}
+
+}  // namespace voc

@@ -17,6 +17,7 @@
 #include "../../include/vocoder_hip.h"
 #include "voc_kernels.h"
 #include "voc_kernels_fast.h"
+#include "voc_filters.h"
 
 #define VOC_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -1106,3 +1107,5 @@ VOC_EXPORT int32_t voc_profile_read(voc_ctx *c, double *ms, int64_t *launches)
     return VOC_OK;
 #endif
 }
+
+#include "vocoder_filters.inc"
