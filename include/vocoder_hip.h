@@ -250,6 +250,43 @@ int32_t voc_gather_frames_dev(voc_ctx *ctx, const double *mag_in, const double *
                               const int64_t *src_dev, int64_t nframes_out, double *mag_out, double *inc_out,
                               int64_t channels, void *stream);
 
+/* ---- chunk-at-a-time streaming (Vocoder.Conduit.process as a conduit, Conduit.hs:46-53) --------
+ * A voc_stream holds what the reference's conduits hold between chunks: the samples
+ * genFramesOfE has not consumed (Frames.hs:36-37), the analysis and synthesis phases
+ * (Conduit.hs:46-47) and sumFramesE's queue of frames that still reach unpublished output
+ * (Frames.hs:48).  Pushing a signal in pieces of any sizes and flushing yields, concatenated,
+ * the samples of one voc_roundtrip call over the whole signal, bit for bit, and publishes
+ * them when sumFramesE would: after the frame with index j, floor(j*H / chunk) chunks are out
+ * (Frames.hs:49-53); voc_stream_flush publishes the rest, zero padded to a whole chunk
+ * (publishRest, Frames.hs:46-47), after which the stream only answers queries.
+ *   filter       chain applied to every frame between analysis and synthesis, or NULL
+ *                (idFilter); must outlive the stream.  playSpeed is not a per-frame chain
+ *                and is not available in streaming form.
+ *   x            [C][x_stride], n new samples per channel (n = 0 is allowed)
+ *   y            [C][y_stride], receives *n_out <= y_cap samples per channel;
+ *                voc_stream_push_length / _flush_length tell *n_out beforehand
+ *                (VOC_ERR_SIZE if y_cap is too small; nothing is consumed then).
+ *   phases       [C][K] host arrays; set before the first push (default zeroPhase), get at
+ *                any time: the phases after the last frame so far.
+ *   voc_stream_leftover  copies the unconsumed samples ([C][out_stride]) and returns their
+ *                count (out = NULL: count only) -- with the two phases this is the triple
+ *                vocoder-audio threads from one source to the next (Audio.hs:31-33).
+ */
+typedef struct voc_stream voc_stream;
+int32_t voc_stream_create(voc_ctx *ctx, int64_t channels, int64_t chunk, voc_filter *filter, voc_stream **out);
+int32_t voc_stream_destroy(voc_stream *s);
+int32_t voc_stream_set_phases(voc_stream *s, const double *ana_phase, const double *syn_phase);
+int32_t voc_stream_get_phases(voc_stream *s, double *ana_phase, double *syn_phase);
+int64_t voc_stream_leftover(voc_stream *s, double *out, int64_t out_stride);
+int64_t voc_stream_push_length(const voc_stream *s, int64_t n);
+int64_t voc_stream_flush_length(const voc_stream *s);
+int32_t voc_stream_push(voc_stream *s, const double *x, int64_t x_stride, int64_t n, double *y, int64_t y_stride,
+                        int64_t y_cap, int64_t *n_out);
+int32_t voc_stream_push_dev(voc_stream *s, const double *x, int64_t x_stride, int64_t n, double *y, int64_t y_stride,
+                            int64_t y_cap, int64_t *n_out, void *stream);
+int32_t voc_stream_flush(voc_stream *s, double *y, int64_t y_stride, int64_t y_cap, int64_t *n_out);
+int32_t voc_stream_flush_dev(voc_stream *s, double *y, int64_t y_stride, int64_t y_cap, int64_t *n_out, void *stream);
+
 /* ---- measurement hook (no counterpart in the reference) ------------------------------------------
  * With profiling on, every kernel launch made through the context is bracketed by HIP events
  * on its launch stream.  voc_profile_read waits for them, adds the elapsed milliseconds and

@@ -1,0 +1,124 @@
+"""Chunk-at-a-time streaming through the C ABI on CPU (host-emulated kernels): pushing a signal in
+pieces gives, concatenated, the bits of one call over the whole signal; chunks are published when
+sumFramesE's state machine (Frames.hs:49-58) publishes them; the state that remains is the
+reference's (leftover, phases) triple."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers import TOL_L2  # noqa: E402
+
+
+def _hann(n):
+    return 0.5 * (1 - np.cos(2 * np.pi * np.arange(n) / n))
+
+
+def published_after(frames, chunk, hop):
+    """Chunks sumFramesE has yielded once `frames` frames were awaited (Frames.hs:49-58)."""
+    sofar = pub = 0
+    for _ in range(frames):
+        while sofar >= chunk:          # process2: publish while a whole chunk lies before the new frame
+            pub += 1
+            sofar -= chunk
+        sofar += hop
+    return pub
+
+
+def _pieces(rng, total, kind):
+    if kind == "one":
+        return [total]
+    if kind == "tiny":
+        cuts = np.sort(rng.integers(0, total + 1, 40))
+    elif kind == "hop":
+        cuts = np.arange(16, total, 16)
+    else:
+        cuts = np.sort(rng.integers(0, total + 1, 6))
+    edges = np.concatenate([[0], cuts, [total]])
+    return list(np.diff(edges))
+
+
+@pytest.mark.parametrize("n,w,hop,chunk", [(64, 64, 16, 16), (64, 48, 16, 40), (64, 64, 16, 200), (32, 32, 32, 32),
+                                           (32, 16, 24, 7), (1024, 1024, 256, 256)])
+@pytest.mark.parametrize("kind", ["one", "few", "tiny", "hop"])
+def test_pushes_concatenate_to_the_batch_result(emu_lib, orc, n, w, hop, chunk, kind):
+    from vocoder_amd import vocoder as V, conduit as Cd, stream as S
+    par = V.VocoderParams(n, hop, _hann(w), lib=emu_lib)
+    rng = np.random.default_rng(n + w + hop + chunk)
+    c, total = 2, w + hop * 23 + 5
+    x = rng.standard_normal((c, total))
+    a0, s0 = rng.uniform(-3, 3, (c, par.K)), rng.uniform(-3, 3, (c, par.K))
+    y_ref, left_ref, (a_ref, s_ref) = Cd.process_with(par, x, phases=(a0, s0), chunk=chunk)
+
+    st = S.Stream(par, c, chunk, ana_phase=a0, syn_phase=s0)
+    outs, pos, frames = [], 0, 0
+    buffered = 0
+    pieces = _pieces(rng, total, kind)
+    for m in pieces:
+        y = st.push(x[:, pos:pos + m])
+        pos += m
+        buffered += m
+        f_new = 0 if buffered < w else (buffered - w) // hop + 1
+        frames += f_new
+        if f_new:
+            buffered = max(buffered - f_new * hop, 0)       # Seq.drop past the end leaves nothing (Frames.hs:36-37)
+        assert y.shape[1] % chunk == 0
+        outs.append(y)
+        assert sum(o.shape[1] for o in outs) == published_after(frames, chunk, hop) * chunk
+    outs.append(st.flush())
+    y = np.concatenate(outs, axis=1)
+    # the framing state machine of the oracle, fed the same pieces, cuts the same frames
+    fr, left = orc.gen_frames_of_e(w, hop, np.split(x[0], np.cumsum(pieces)[:-1]))
+    assert fr.shape[0] == frames and np.array_equal(st.leftover()[0], left)
+    if hop > w and kind != "one":
+        # a hop longer than the window drops samples between frames; when a piece ends inside such
+        # a gap the reference restarts its hop grid at the next piece, so the result legitimately
+        # depends on the pieces and is not the one-piece result
+        assert y.shape[1] == -(-((frames - 1) * hop + w) // chunk) * chunk
+        return
+    assert y.shape == y_ref.shape
+    assert np.array_equal(y, y_ref)
+    a, s = st.phases()
+    assert np.array_equal(a, a_ref) and np.array_equal(s, s_ref)
+    assert np.array_equal(st.leftover(), left_ref)
+
+
+def test_stream_with_filter_matches_filtered_pipeline(emu_lib):
+    import torch
+    from vocoder_amd import vocoder as V, conduit as Cd, stream as S, filter as Fl
+    par = V.VocoderParams(128, 32, _hann(128), lib=emu_lib)
+    filt = (Fl.pitch_shift_interpolate(1.5) >> Fl.lowpass_butterworth(2.0, 4000.0)).bind(par, 48000.0 / 128)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((1, 128 + 32 * 30 + 3))
+    y_ref, _, s_ref = Cd.process_filter_dev(par, filt, torch.from_numpy(x))
+    st = S.Stream(par, 1, filt=filt)
+    outs = [st.push(x[:, :200]), st.push(x[:, 200:777]), st.push(x[:, 777:]), st.flush()]
+    assert np.array_equal(np.concatenate(outs, axis=1), y_ref.numpy())
+    assert np.array_equal(st.phases()[1], s_ref.numpy())
+
+
+def test_stream_argument_errors(emu_lib):
+    import ctypes as C
+    from vocoder_amd import vocoder as V, stream as S, filter as Fl
+    par = V.VocoderParams(64, 16, _hann(64), lib=emu_lib)
+    d = emu_lib.dll
+    h = C.c_void_p()
+    assert d.voc_stream_create(par.handle, 0, 16, None, C.byref(h)) == -1
+    assert d.voc_stream_create(par.handle, 1, 0, None, C.byref(h)) == -1
+    st = S.Stream(par, 1)
+    x = np.zeros((1, 200))
+    got = C.c_int64(0)
+    need = d.voc_stream_push_length(st._h, 200)
+    assert need == ((200 - 64) // 16) * 16
+    y = np.zeros((1, 8))
+    assert d.voc_stream_push(st._h, x.ctypes.data_as(C.c_void_p), 200, 200, y.ctypes.data_as(C.c_void_p), 8, 8,
+                             C.byref(got)) == -5          # output buffer too small: nothing consumed
+    assert got.value == need and d.voc_stream_push_length(st._h, 200) == need
+    assert st.push(x).shape == (1, need)
+    st.flush()
+    with pytest.raises(V.VocoderError):
+        st.push(x)                                        # a flushed stream takes no more input
+    with pytest.raises(ValueError):
+        S.Stream(par, 1, filt=Fl.play_speed(2).bind(par, 1.0))

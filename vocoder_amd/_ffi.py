@@ -57,6 +57,17 @@ SIGNATURES = {
     "voc_play_speed_frames": (_i64, [_i64, _i64, _i64]),
     "voc_play_speed_map": (_i32, [_i64, _i64, _i64, _vp, _i64]),
     "voc_gather_frames_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
+    "voc_stream_create": (_i32, [_vp, _i64, _i64, _vp, C.POINTER(_vp)]),
+    "voc_stream_destroy": (_i32, [_vp]),
+    "voc_stream_set_phases": (_i32, [_vp, _vp, _vp]),
+    "voc_stream_get_phases": (_i32, [_vp, _vp, _vp]),
+    "voc_stream_leftover": (_i64, [_vp, _vp, _i64]),
+    "voc_stream_push_length": (_i64, [_vp, _i64]),
+    "voc_stream_flush_length": (_i64, [_vp]),
+    "voc_stream_push": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, C.POINTER(_i64)]),
+    "voc_stream_push_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, C.POINTER(_i64), _vp]),
+    "voc_stream_flush": (_i32, [_vp, _vp, _i64, _i64, C.POINTER(_i64)]),
+    "voc_stream_flush_dev": (_i32, [_vp, _vp, _i64, _i64, C.POINTER(_i64), _vp]),
     "voc_profile_enable": (_i32, [_vp, _i32]),
     "voc_profile_read": (_i32, [_vp, _vp, _vp]),
     "voc_roundtrip_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),

@@ -1109,3 +1109,4 @@ VOC_EXPORT int32_t voc_profile_read(voc_ctx *c, double *ms, int64_t *launches)
 }
 
 #include "vocoder_filters.inc"
+#include "vocoder_stream.inc"
