@@ -4,9 +4,9 @@
 //
 // A filter chain (composeFilters, Filter.hs:54-55) is a short program of row operations.  One
 // workgroup takes one STFT row (one frame of one channel: K moduli and K phase increments),
-// keeps it in LDS, runs every operation of the chain on it in order and writes it back, so a
-// chain of any length reads and writes the STFT once.  Rows too long for LDS (K > 5000) use a
-// per-workgroup scratch area in global memory through the same code.
+// keeps it in registers, runs every operation of the chain on it in order and writes it back, so
+// a chain of any length reads and writes the STFT once; operations that read neighbouring bins
+// exchange the row through LDS.
 //
 // Rounding follows the reference operation by operation (compiled with -ffp-contract=off):
 // gains are one multiply per filter in chain order, interpolation is (1-k)*v[i] + k*v[i+1] with
@@ -75,72 +75,137 @@ VOC_DEV void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, u
     *r1 = c1;
 }
 
-__global__ __launch_bounds__(256) void filter_rows_kernel(Params p, FilterProg prog, double *__restrict__ mag,
-                                                          double *__restrict__ inc, long long ldk, long long rows,
-                                                          double *gscratch)
+// convolve_at with every term multiplied by 1/s and corrected once instead of divided: a few
+// ulp-of-a-term cheaper than the exact quotient; used inside the envelope only, whose log / exp are
+// not bit-reproducible across math libraries anyway.
+VOC_DEV double convolve_fast_at(const double *mag, int K, const double *ker, int len, double s, double rs, int k)
 {
+    const int h = len / 2;
+    double acc = 0.0;
+    for (int i = 0; i < len; ++i) {
+        const int j = i + k - h;
+        const double a = ker[i] * ((j >= 0 && j < K) ? mag[j] : 0.0);
+        const double q = a * rs;
+        acc = acc + fma(fma(-s, q, a), rs, q);
+    }
+    return acc;
+}
+
+template <int LOG2M>
+struct FiltCfg {
+    static constexpr int M = 1 << LOG2M;
+    static constexpr int T = (M / 8) < 64 ? 64 : ((M / 8) > 1024 ? 1024 : (M / 8));  // threads per row
+    static constexpr int NE = M / T + 1;  // bins per thread: k = tid + T*j, the last slot holds bin M (thread 0 only)
+};
+
+// One workgroup per STFT row at a time.  The row lives in registers (thread t holds bins t + T*j);
+// operations that read neighbouring bins stage it through LDS (2 * (K+1) doubles, only allocated
+// when the chain holds such an operation).
+template <int LOG2M>
+__global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p, FilterProg prog,
+                                                                        double *__restrict__ mag,
+                                                                        double *__restrict__ inc, long long ldk,
+                                                                        long long rows)
+{
+    using Cf = FiltCfg<LOG2M>;
+    constexpr int T = Cf::T, NE = Cf::NE, K = Cf::M + 1;
     VOC_SMEM(double, lds);
-    const int K = p.K;
-    const int Kp = (K + 1) & ~1;
-    double *buf = gscratch ? gscratch + (size_t)blockIdx.x * 4 * Kp : lds;
-    double *cm = buf, *ci = buf + Kp, *tm = buf + 2 * Kp, *ti = buf + 3 * Kp;
-    const int tid = threadIdx.x, T = blockDim.x;
+    double *lm = lds, *li = lds + ((K + 1) & ~1);
+    const int tid = threadIdx.x;
     const double ee = 5.9604644775390625e-08;  // 2**(-24), Filter.hs:147
     for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
         double *mrow = mag + row * ldk, *irow = inc + row * ldk;
-        for (int k = tid; k < K; k += T) {
-            cm[k] = mrow[k];
-            ci[k] = irow[k];
+        double m[NE], ic[NE];
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const int k = tid + T * j;
+            m[j] = 0.0;
+            ic[j] = 0.0;
+            if (k < K) {
+                m[j] = mrow[k];
+                ic[j] = irow[k];
+            }
         }
-        __syncthreads();
         for (int o = 0; o < prog.n; ++o) {
             const FilterOp op = prog.op[o];
             switch (op.kind) {
             case FOP_GAIN:  // linearAmplitudeFilter (Filter.hs:76-77): mag * gain, phase increments kept
-                for (int k = tid; k < K; k += T) cm[k] = cm[k] * op.table[k];
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    const int k = tid + T * j;
+                    if (k < K) m[j] = m[j] * op.table[k];
+                }
                 break;
-            case FOP_PITCH: {  // pitchShiftInterpolate (Filter.hs:128-129)
-                for (int k = tid; k < K; k += T) {
-                    tm[k] = interpolate_at(cm, K, op.a, k);
-                    ti[k] = interpolate_at(ci, K, op.a, k) / op.a;
+            case FOP_PITCH:  // pitchShiftInterpolate (Filter.hs:128-129)
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    const int k = tid + T * j;
+                    if (k < K) { lm[k] = m[j]; li[k] = ic[j]; }
                 }
-                double *t = cm; cm = tm; tm = t;
-                t = ci; ci = ti; ti = t;
-            } break;
-            case FOP_CONV: {  // convolutionFilter (Filter.hs:140-141): amplitudeFilter0 zeroes ph_inc
-                for (int k = tid; k < K; k += T) {
-                    tm[k] = convolve_at(cm, K, op.table, op.len, op.a, k);
-                    ci[k] = 0.0;
-                }
-                double *t = cm; cm = tm; tm = t;
-            } break;
-            case FOP_ENVELOPE: {  // envelopeFilter (Filter.hs:144-152)
-                for (int k = tid; k < K; k += T) cm[k] = log(cm[k] + ee);
                 __syncthreads();
-                for (int k = tid; k < K; k += T) {
-                    tm[k] = exp(convolve_at(cm, K, op.table, op.len, op.a, k)) + (-ee);
-                    ci[k] = 0.0;
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    const int k = tid + T * j;
+                    if (k < K) {
+                        m[j] = interpolate_at(lm, K, op.a, k);
+                        ic[j] = interpolate_at(li, K, op.a, k) / op.a;
+                    }
                 }
-                double *t = cm; cm = tm; tm = t;
+                __syncthreads();
+                break;
+            case FOP_CONV:  // convolutionFilter (Filter.hs:140-141): amplitudeFilter0 zeroes ph_inc
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    const int k = tid + T * j;
+                    if (k < K) lm[k] = m[j];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    const int k = tid + T * j;
+                    if (k < K) m[j] = convolve_at(lm, K, op.table, op.len, op.a, k);
+                    ic[j] = 0.0;
+                }
+                __syncthreads();
+                break;
+            case FOP_ENVELOPE: {  // envelopeFilter (Filter.hs:144-152)
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    const int k = tid + T * j;
+                    if (k < K) lm[k] = log(m[j] + ee);
+                }
+                __syncthreads();
+                const double rs = 1.0 / op.a;
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    const int k = tid + T * j;
+                    if (k < K) m[j] = exp(convolve_fast_at(lm, K, op.table, op.len, op.a, rs, k)) + (-ee);
+                    ic[j] = 0.0;
+                }
+                __syncthreads();
             } break;
             case FOP_RANDOM_PHASE:  // randomPhaseFilter (Filter.hs:156-157): ph_inc uniform on [0, 2 pi)
-                for (int k = tid; k < K; k += T) {
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    const int k = tid + T * j;
                     unsigned r0, r1;
                     philox4x32_10((unsigned)k, (unsigned)row, (unsigned)((unsigned long long)row >> 32), (unsigned)o,
                                   (unsigned)op.seed, (unsigned)(op.seed >> 32), &r0, &r1);
                     const unsigned long long bits = (((unsigned long long)r0 << 32) | r1) >> 11;
-                    ci[k] = ((double)bits * 1.1102230246251565e-16) * kTwoPi;  // 53 random bits * 2^-53 * 2 pi
+                    ic[j] = ((double)bits * 1.1102230246251565e-16) * kTwoPi;  // 53 random bits * 2^-53 * 2 pi
                 }
                 break;
             default: break;
             }
-            __syncthreads();
         }
-        for (int k = tid; k < K; k += T) {
-            mrow[k] = cm[k];
-            irow[k] = ci[k];
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const int k = tid + T * j;
+            if (k < K) {
+                mrow[k] = m[j];
+                irow[k] = ic[j];
+            }
         }
-        __syncthreads();
     }
 }
 
