@@ -4,7 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from vocoder_amd import vocoder as V, conduit as Cd, window as Wn
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-N = W = 4096; H = 1024; L = 2_880_000
+N = W = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+H = int(sys.argv[3]) if len(sys.argv) > 3 else N // 4
+L = 2_880_000
 from vocoder_amd._ffi import Library
 lib = Library(os.environ['VOC_LIB']) if os.environ.get('VOC_LIB') else None   # development: time an experimental build
 par = V.VocoderParams(N, H, Wn.hann_window(W), lib=lib)
@@ -24,7 +26,7 @@ for it in range(3):
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
 ms = np.zeros(4); cnt = np.zeros(4, dtype=np.int64)
 par.lib.dll.voc_profile_read(par.handle, ms.ctypes.data, cnt.ctypes.data)
-print(f'C={C} frames={C*F} {dt*1e3:.1f} ms/step {C*F/dt/1e6:.2f} Mframes/s | analysis {ms[0]/max(cnt[0],1):.1f} ms carry {ms[1]/max(cnt[1],1):.1f} synthesis {ms[2]/max(cnt[2],1):.1f} ms', flush=True)
+print(f'N={N} H={H} bytes/frame={16*H+32*(N//2+1)} roofline_frac={C*F/dt*(16*H+32*(N//2+1))/8e12:.3f} C={C} frames={C*F} {dt*1e3:.1f} ms/step {C*F/dt/1e6:.2f} Mframes/s | analysis {ms[0]/max(cnt[0],1):.1f} ms carry {ms[1]/max(cnt[1],1):.1f} synthesis {ms[2]/max(cnt[2],1):.1f} ms', flush=True)
 aph.zero_(); sph.zero_()
 Cd.process_dev(par, x, y, aph, sph, workspace=ws); torch.cuda.synchronize()
-print('identity err', (y[:, 4096:L - 4096] - x[:, 4096:L - 4096]).abs().max().item())
+print('identity err', (y[:8, N:L - N] - x[:8, N:L - N]).abs().max().item())

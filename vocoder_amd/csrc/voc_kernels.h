@@ -726,13 +726,15 @@ __global__ void phase_carry_kernel(Params p, const double *__restrict__ inc, lon
     long long next = (long long)tile_len - halo;  // frame count after which tile 1 starts
     int t = 1;
     long long f = 0;
-    // four loads in flight per thread; the additions stay in frame order
-    for (; f + 4 <= F && t < tiles; f += 4) {
-        const double d0 = src[f * ldk], d1 = src[(f + 1) * ldk], d2 = src[(f + 2) * ldk], d3 = src[(f + 3) * ldk];
-        const double dd[4] = {d0 * p.hop_d, d1 * p.hop_d, d2 * p.hop_d, d3 * p.hop_d};
+    // sixteen loads in flight per thread (the chain is latency bound when there are few channels);
+    // the additions stay in frame order
+    for (; f + 16 <= F && t < tiles; f += 16) {
+        double dd[16];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            ph = ph + dd[u];
+        for (int u = 0; u < 16; ++u) dd[u] = src[(f + u) * ldk];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            ph = ph + dd[u] * p.hop_d;
             if (f + u + 1 == next) {
                 if (t < tiles) carry[(c * tiles + t) * p.K + k] = ph;
                 ++t;
@@ -764,12 +766,12 @@ __global__ void phase_advance_kernel(Params p, const double *__restrict__ inc, l
     double ph = phase_io[g];
     const double *src = inc + c * F * ldk + k;
     long long f = 0;
-    for (; f + 4 <= F; f += 4) {
-        const double d0 = src[f * ldk], d1 = src[(f + 1) * ldk], d2 = src[(f + 2) * ldk], d3 = src[(f + 3) * ldk];
-        ph = ph + d0 * p.hop_d;
-        ph = ph + d1 * p.hop_d;
-        ph = ph + d2 * p.hop_d;
-        ph = ph + d3 * p.hop_d;
+    for (; f + 16 <= F; f += 16) {
+        double dd[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) dd[u] = src[(f + u) * ldk];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) ph = ph + dd[u] * p.hop_d;
     }
     for (; f < F; ++f) ph = ph + src[f * ldk] * p.hop_d;
     phase_io[g] = ph;
