@@ -20,6 +20,8 @@ module Vocoder.HIP
     ( VocoderParams, vocoderParams, vocFrameLength, vocInputFrameLength, vocFreqFrameLength
     , vocHopSize, vocWindow, analysisStage, analysisBlock, synthesisStage, synthesisBlock
     , zeroPhase, volumeCoeff, processChannels
+    , Moduli, Phase, PhaseInc, Frame, Window, STFTFrame
+    , vocCtx, check   -- for the sibling modules Vocoder.HIP.Filter
     ) where
 
 import Control.Monad (when)

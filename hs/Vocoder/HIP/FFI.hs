@@ -62,3 +62,42 @@ foreign import ccall safe "voc_sum_frames" c_voc_sum_frames
 foreign import ccall safe "voc_roundtrip" c_voc_roundtrip
     :: Ptr VocCtx -> Ptr Double -> Int64 -> Int64 -> Int64 -> Int64 -> Ptr Double -> Int64
     -> Ptr Double -> Ptr Double -> Ptr Double -> Int64 -> IO Int32
+
+-- * Filters (Vocoder.Filter) on host arrays mag[C*F*K], ph_inc[C*F*K]
+
+data VocFilter
+
+foreign import ccall safe   "voc_filter_create"  c_voc_filter_create
+    :: Ptr VocCtx -> Double -> Ptr (Ptr VocFilter) -> IO Int32
+foreign import ccall unsafe "&voc_filter_destroy" p_voc_filter_destroy :: FunPtr (Ptr VocFilter -> IO ())
+-- | kind (VOC_FILTER_* in vocoder_hip.h), params, nparams
+foreign import ccall safe   "voc_filter_append"  c_voc_filter_append
+    :: Ptr VocFilter -> Int32 -> Ptr Double -> Int32 -> IO Int32
+foreign import ccall safe   "voc_filter_apply"   c_voc_filter_apply
+    :: Ptr VocFilter -> Ptr Double -> Ptr Double -> Int64 -> Int64 -> IO Int32
+
+-- * playSpeed (Vocoder.Conduit.Filter): numerator, denominator, input frames
+foreign import ccall unsafe "voc_play_speed_frames" c_voc_play_speed_frames :: Int64 -> Int64 -> Int64 -> IO Int64
+foreign import ccall unsafe "voc_play_speed_map"    c_voc_play_speed_map
+    :: Int64 -> Int64 -> Int64 -> Ptr Int64 -> Int64 -> IO Int32
+
+-- * Chunk-at-a-time streaming (Vocoder.Conduit.process as a conduit)
+
+data VocStream
+
+foreign import ccall safe   "voc_stream_create"  c_voc_stream_create
+    :: Ptr VocCtx -> Int64 -> Int64 -> Ptr VocFilter -> Ptr (Ptr VocStream) -> IO Int32
+foreign import ccall unsafe "&voc_stream_destroy" p_voc_stream_destroy :: FunPtr (Ptr VocStream -> IO ())
+foreign import ccall safe   "voc_stream_set_phases" c_voc_stream_set_phases
+    :: Ptr VocStream -> Ptr Double -> Ptr Double -> IO Int32
+foreign import ccall safe   "voc_stream_get_phases" c_voc_stream_get_phases
+    :: Ptr VocStream -> Ptr Double -> Ptr Double -> IO Int32
+foreign import ccall safe   "voc_stream_leftover"   c_voc_stream_leftover
+    :: Ptr VocStream -> Ptr Double -> Int64 -> IO Int64
+foreign import ccall unsafe "voc_stream_push_length"  c_voc_stream_push_length :: Ptr VocStream -> Int64 -> IO Int64
+foreign import ccall unsafe "voc_stream_flush_length" c_voc_stream_flush_length :: Ptr VocStream -> IO Int64
+-- | x, x_stride, n, y, y_stride, y_cap, n_out
+foreign import ccall safe   "voc_stream_push" c_voc_stream_push
+    :: Ptr VocStream -> Ptr Double -> Int64 -> Int64 -> Ptr Double -> Int64 -> Int64 -> Ptr Int64 -> IO Int32
+foreign import ccall safe   "voc_stream_flush" c_voc_stream_flush
+    :: Ptr VocStream -> Ptr Double -> Int64 -> Int64 -> Ptr Int64 -> IO Int32
