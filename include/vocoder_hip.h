@@ -271,9 +271,22 @@ int32_t voc_gather_frames_dev(voc_ctx *ctx, const double *mag_in, const double *
  *   voc_stream_leftover  copies the unconsumed samples ([C][out_stride]) and returns their
  *                count (out = NULL: count only) -- with the two phases this is the triple
  *                vocoder-audio threads from one source to the next (Audio.hs:31-33).
+ * voc_stream_create_mode(.., VOC_STREAM_DUNAI, ..) follows Vocoder.Dunai.process instead
+ * (vocoder-dunai/src/Vocoder/Dunai.hs:46-48): the stream starts from ((W-1) div H)*H zeros
+ * (framesOfS, Dunai.hs:58-69), every push must be a multiple of the hop and returns exactly as
+ * many samples as it was given (sumFramesWithLengthS, Dunai.hs:76-85), the volume correction is
+ * applied to the summed samples, not to the moduli (Dunai.hs:41-42,48); `chunk` is ignored and
+ * there is nothing to flush.
+ * voc_stream_set_filter swaps the chain between pushes (each source of a concatenation has its
+ * own filter, vocoder-audio/src/Vocoder/Audio.hs:48-55,64-69).
+ * Destroy streams and filters before the context they were created on.
  */
 typedef struct voc_stream voc_stream;
+enum { VOC_STREAM_CONDUIT = 0, VOC_STREAM_DUNAI = 1 };
 int32_t voc_stream_create(voc_ctx *ctx, int64_t channels, int64_t chunk, voc_filter *filter, voc_stream **out);
+int32_t voc_stream_create_mode(voc_ctx *ctx, int64_t channels, int64_t chunk, voc_filter *filter, int32_t mode,
+                               voc_stream **out);
+int32_t voc_stream_set_filter(voc_stream *s, voc_filter *filter);
 int32_t voc_stream_destroy(voc_stream *s);
 int32_t voc_stream_set_phases(voc_stream *s, const double *ana_phase, const double *syn_phase);
 int32_t voc_stream_get_phases(voc_stream *s, double *ana_phase, double *syn_phase);

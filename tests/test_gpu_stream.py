@@ -50,3 +50,23 @@ def test_stream_device_entry_with_filter(gpu_lib):
     y = np.concatenate([o.cpu().numpy() for o in outs] + [st.flush()], axis=1)
     assert np.array_equal(y, y_ref.cpu().numpy())
     assert np.array_equal(st.phases()[1], s_ref.cpu().numpy())
+
+
+def test_dunai_mode_on_device_matches_oracle(gpu_lib, orc):
+    """Vocoder.Dunai.process conventions (Dunai.hs:46-48) at N=4096: zero pre-pad, ticks in
+    multiples of the hop, as many samples out as in, volume correction on the samples."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_stream_cpu import _oracle_dunai
+    from vocoder_amd import vocoder as V, stream as S
+    n, hop = 4096, 1024
+    win = _hann(n)
+    par = V.VocoderParams(n, hop, win, lib=gpu_lib)
+    rng = np.random.default_rng(8)
+    ticks = [rng.standard_normal(hop * m) for m in (4, 1, 7, 0, 12)]
+    ref, aph, sph = _oracle_dunai(orc, n, hop, win, ticks)
+    st = S.Stream(par, 1, dunai=True)
+    got = [st.push(t)[0] for t in ticks]
+    y, r = np.concatenate(got), np.concatenate(ref)
+    assert y.shape == r.shape
+    assert np.linalg.norm(y - r) / np.linalg.norm(r) <= 1e-9

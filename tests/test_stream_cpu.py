@@ -122,3 +122,80 @@ def test_stream_argument_errors(emu_lib):
         st.push(x)                                        # a flushed stream takes no more input
     with pytest.raises(ValueError):
         S.Stream(par, 1, filt=Fl.play_speed(2).bind(par, 1.0))
+
+
+def _oracle_dunai(orc, n, hop, window, ticks):
+    """Vocoder.Dunai.process par (arr id) on one channel, from oracle pieces (Dunai.hs:46-48):
+    framesOfS >>> analysis >>> synthesis, sumFramesWithLengthS, volumeFix on the samples."""
+    w = len(window)
+    k = n // 2 + 1
+    per_tick = orc.frames_of_s(w, hop, ticks)
+    aph, sph = np.zeros(k), np.zeros(k)
+    out_frames = []
+    for fr in per_tick:
+        if fr.shape[0] == 0:
+            out_frames.append(np.empty((0, w)))
+            continue
+        aph, mag, inc = orc.analysis_stage(n, hop, window, aph, fr)
+        sph, res = orc.synthesis_stage(n, hop, window, sph, mag, inc)
+        out_frames.append(res)
+    outs = orc.sum_frames_s(hop, out_frames, [t.size for t in ticks])
+    vc = orc.volume_coeff(hop, window)
+    return [o * vc for o in outs], aph, sph
+
+
+@pytest.mark.parametrize("n,w,hop", [(64, 64, 16), (64, 40, 16), (32, 32, 32), (1024, 1024, 256)])
+def test_dunai_mode_matches_oracle_ticks(emu_lib, orc, n, w, hop):
+    from vocoder_amd import vocoder as V, stream as S
+    win = _hann(w)
+    par = V.VocoderParams(n, hop, win, lib=emu_lib)
+    rng = np.random.default_rng(n + w)
+    sizes = [hop * m for m in (3, 1, 0, 5, 2, 8)]
+    ticks = [rng.standard_normal(m) for m in sizes]
+    ref, aph, sph = _oracle_dunai(orc, n, hop, win, ticks)
+    st = S.Stream(par, 1, dunai=True)
+    for t, r in zip(ticks, ref):
+        y = st.push(t)
+        assert y.shape == (1, t.size)                      # as many samples out as in
+        if t.size:
+            scale = max(np.abs(np.concatenate(ref)).max(), 1e-300)
+            assert np.abs(y[0] - r).max() <= 1e-12 * scale
+    a, s = st.phases()
+    assert np.abs(a[0] - aph).max() <= 1e-9
+    d = np.abs(s[0] - sph) % (2 * np.pi)
+    assert np.minimum(d, 2 * np.pi - d).max() <= 1e-9
+    with pytest.raises(V.VocoderError):
+        st.push(np.zeros(hop + 1))                        # not a multiple of the hop (Dunai.hs:45)
+
+
+def test_concatenated_sources_with_their_own_filters(emu_lib, orc):
+    """concatenateV (Audio.hs:60-69): the leftover and phases of source 1 flow into source 2, each
+    source runs its own filter, all frames feed one overlap-add."""
+    from vocoder_amd import vocoder as V, stream as S, filter as Fl
+    n, hop = 128, 32
+    win = _hann(n)
+    par = V.VocoderParams(n, hop, win, lib=emu_lib)
+    step = 48000.0 / n
+    rng = np.random.default_rng(21)
+    x1, x2 = rng.standard_normal(n + hop * 9 + 7), rng.standard_normal(hop * 11 + 3)
+    f1 = Fl.lowpass_brickwall(6000.0).bind(par, step)
+    f2 = Fl.pitch_shift_interpolate(1.25).bind(par, step)
+    st = S.Stream(par, 1, filt=f1)
+    outs = [st.push(x1)]
+    st.set_filter(f2)
+    outs += [st.push(x2), st.flush()]
+    y = np.concatenate(outs, axis=1)[0]
+
+    # oracle: frames of (x1), then frames of (leftover1 ++ x2); one phase chain; one overlap-add
+    k = n // 2 + 1
+    fr1, left1 = orc.gen_frames_of_e(n, hop, [x1])
+    fr2, _ = orc.gen_frames_of_e(n, hop, [x2], q0=left1)
+    vc = orc.volume_coeff(hop, win)
+    aph, m1, i1 = orc.analysis_stage(n, hop, win, np.zeros(k), fr1)
+    aph, m2, i2 = orc.analysis_stage(n, hop, win, aph, fr2)
+    m1, i1 = orc.apply_filter(step, [("lowpass_brickwall", 6000.0)], m1 * vc, i1)
+    m2, i2 = orc.apply_filter(step, [("pitch_shift", 1.25)], m2 * vc, i2)
+    _, frames = orc.synthesis_stage(n, hop, win, np.zeros(k), np.concatenate([m1, m2]), np.concatenate([i1, i2]))
+    ref = orc.sum_frames_e(hop, hop, list(frames)).ravel()
+    assert y.size == ref.size
+    assert np.linalg.norm(y - ref) / np.linalg.norm(ref) <= TOL_L2

@@ -777,6 +777,15 @@ __global__ void phase_advance_kernel(Params p, const double *__restrict__ inc, l
     phase_io[g] = ph;
 }
 
+// rows[r][0 .. width) *= factor, rows `pitch` doubles apart (volumeFix on samples, Dunai.hs:41-42)
+__global__ void scale_rows_kernel(double *__restrict__ rows, long long pitch, long long width, long long total, double factor)
+{
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const long long r = g / width, i = g % width;
+        rows[r * pitch + i] = rows[r * pitch + i] * factor;
+    }
+}
+
 // ------------------------------------------------------------------ step-level, framing, overlap-add
 
 // analysisStep over B independent frames (Vocoder.hs:158-163)

@@ -15,8 +15,10 @@ __all__ = ["Stream"]
 
 class Stream:
     def __init__(self, par: VocoderParams, channels: int = 1, chunk: int | None = None, filt=None,
-                 ana_phase=None, syn_phase=None):
-        """filt: a `vocoder_amd.filter.BoundFilter` made of per-frame stages only, or None."""
+                 ana_phase=None, syn_phase=None, dunai: bool = False):
+        """filt: a `vocoder_amd.filter.BoundFilter` made of per-frame stages only, or None.
+        dunai=True: the conventions of Vocoder.Dunai.process (vocoder-dunai/src/Vocoder/Dunai.hs:46-48):
+        zero pre-pad, pushes in multiples of the hop, as many samples out as in."""
         self.par, self.channels = par, int(channels)
         self.chunk = par.H if chunk is None else int(chunk)
         fh = None
@@ -27,12 +29,24 @@ class Stream:
             fh = filt.parts[0][1]._h if kinds else None
         self._filt = filt                         # keeps the device chain alive
         h = C.c_void_p()
-        par.lib.check(par.lib.dll.voc_stream_create(par.handle, self.channels, self.chunk, fh, C.byref(h)), par.handle)
+        par.lib.check(par.lib.dll.voc_stream_create_mode(par.handle, self.channels, self.chunk, fh, 1 if dunai else 0,
+                                                         C.byref(h)), par.handle)
         self._h = h
         if ana_phase is not None or syn_phase is not None:
             a = np.zeros((self.channels, par.K)) if ana_phase is None else _f64(ana_phase).reshape(self.channels, par.K)
             s = np.zeros((self.channels, par.K)) if syn_phase is None else _f64(syn_phase).reshape(self.channels, par.K)
             par.lib.check(par.lib.dll.voc_stream_set_phases(h, _p(a), _p(s)), par.handle)
+
+    def set_filter(self, filt):
+        """Swaps the per-frame filter chain between pushes (a new source of a concatenation)."""
+        fh = None
+        if filt is not None:
+            kinds = [k for k, _ in filt.parts]
+            if kinds not in ([], ["chain"]):
+                raise ValueError("a stream takes one chain of per-frame filters")
+            fh = filt.parts[0][1]._h if kinds else None
+        self.par.lib.check(self.par.lib.dll.voc_stream_set_filter(self._h, fh), self.par.handle)
+        self._filt = filt
 
     def push(self, x) -> np.ndarray:
         """x: (n,) for one channel or (C, n).  Returns the samples published by this push, (C, m)."""
