@@ -250,6 +250,17 @@ int32_t voc_gather_frames_dev(voc_ctx *ctx, const double *mag_in, const double *
                               const int64_t *src_dev, int64_t nframes_out, double *mag_out, double *inc_out,
                               int64_t channels, void *stream);
 
+/* ---- interleaved <-> planar samples ---------------------------------------------------------------
+ * vocoder-audio frames interleaved multi-channel audio (frames of W*channels samples at hops of
+ * H*channels) and de-interleaves every frame (vocoder-audio/src/Vocoder/Audio.hs:51-55); the
+ * library is planar, so a caller with interleaved device buffers converts once per buffer:
+ * inter[i*channels + c] <-> planar[c*stride + i], i < n.
+ */
+int32_t voc_deinterleave_dev(voc_ctx *ctx, const double *inter, int64_t n, int64_t channels, double *planar,
+                             int64_t stride, void *stream);
+int32_t voc_interleave_dev(voc_ctx *ctx, const double *planar, int64_t stride, int64_t n, int64_t channels,
+                           double *inter, void *stream);
+
 /* ---- chunk-at-a-time streaming (Vocoder.Conduit.process as a conduit, Conduit.hs:46-53) --------
  * A voc_stream holds what the reference's conduits hold between chunks: the samples
  * genFramesOfE has not consumed (Frames.hs:36-37), the analysis and synthesis phases

@@ -164,3 +164,22 @@ def test_filtered_pipeline_matches_oracle(par, orc, chain, speed):
         assert y.shape[1] == ref["y"].size
         err = np.linalg.norm(y[c].numpy() - ref["y"]) / max(np.linalg.norm(ref["y"]), 1e-300)
         assert err <= TOL_L2, err
+
+
+def test_interleaved_framing_equals_planar_per_channel(par, orc):
+    """vocoder-audio cuts frames of W*C interleaved samples at hops of H*C and splits each frame
+    per channel (Audio.hs:51-55): the same frames as cutting each planar channel at (W, H)."""
+    import torch
+    from vocoder_amd import conduit as Cd
+    rng = np.random.default_rng(13)
+    c, n = 3, 128 + 32 * 6 + 5
+    planar = rng.integers(-1000, 1000, (c, n)).astype(np.float64)
+    inter = planar.T.reshape(-1).copy()
+    got = Cd.deinterleave_dev(par, torch.from_numpy(inter), c)
+    assert np.array_equal(got.numpy(), planar)
+    assert np.array_equal(Cd.interleave_dev(par, got).numpy(), inter)
+    fr_inter, left = orc.gen_frames_of_e(128 * c, 32 * c, [inter])          # the reference's framing
+    for ch in range(c):
+        fr_ch, left_ch = orc.gen_frames_of_e(128, 32, [planar[ch]])
+        assert np.array_equal(fr_inter.reshape(-1, 128, c)[:, :, ch], fr_ch)
+        assert np.array_equal(left.reshape(-1, c)[:, ch], left_ch)

@@ -57,6 +57,8 @@ SIGNATURES = {
     "voc_play_speed_frames": (_i64, [_i64, _i64, _i64]),
     "voc_play_speed_map": (_i32, [_i64, _i64, _i64, _vp, _i64]),
     "voc_gather_frames_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
+    "voc_deinterleave_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _vp]),
+    "voc_interleave_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "voc_stream_create": (_i32, [_vp, _i64, _i64, _vp, C.POINTER(_vp)]),
     "voc_stream_create_mode": (_i32, [_vp, _i64, _i64, _vp, _i32, C.POINTER(_vp)]),
     "voc_stream_set_filter": (_i32, [_vp, _vp]),

@@ -16,7 +16,7 @@ import numpy as np
 from .vocoder import VocoderParams, _f64, _p, zero_phase
 
 __all__ = ["num_frames", "leftover_length", "ola_length", "frames_of_e", "sum_frames_e", "process_with",
-           "process", "process_dev", "roundtrip_workspace_bytes", "process_filter_dev"]
+           "process", "process_dev", "roundtrip_workspace_bytes", "process_filter_dev", "deinterleave_dev", "interleave_dev"]
 
 
 def num_frames(par: VocoderParams, length: int) -> int:
@@ -151,3 +151,24 @@ def process_filter_dev(par: VocoderParams, filt, x, length: int | None = None, c
         par._call("voc_synthesis_signal_dev", C.c_void_p(mag.data_ptr()), C.c_void_p(inc.data_ptr()), ldk, fo, c,
                   C.c_void_p(sph.data_ptr()), C.c_void_p(y.data_ptr()), y.stride(0), n, st)
     return y, aph, sph
+
+
+def deinterleave_dev(par: VocoderParams, inter, channels: int):
+    """Interleaved samples (n*channels,) -> planar (channels, n), device tensors (Audio.hs:51-55 splits per frame;
+    here once per buffer)."""
+    import torch
+    n = inter.numel() // channels
+    out = torch.empty((channels, n), dtype=torch.float64, device=inter.device)
+    st = C.c_void_p(torch.cuda.current_stream(inter.device).cuda_stream) if inter.is_cuda else None
+    par._call("voc_deinterleave_dev", C.c_void_p(inter.data_ptr()), n, channels, C.c_void_p(out.data_ptr()), n, st)
+    return out
+
+
+def interleave_dev(par: VocoderParams, planar):
+    """Planar (channels, n) -> interleaved (n*channels,), device tensors."""
+    import torch
+    c, n = planar.shape
+    out = torch.empty(n * c, dtype=torch.float64, device=planar.device)
+    st = C.c_void_p(torch.cuda.current_stream(planar.device).cuda_stream) if planar.is_cuda else None
+    par._call("voc_interleave_dev", C.c_void_p(planar.data_ptr()), planar.stride(0), n, c, C.c_void_p(out.data_ptr()), st)
+    return out

@@ -786,6 +786,22 @@ __global__ void scale_rows_kernel(double *__restrict__ rows, long long pitch, lo
     }
 }
 
+// Interleaved <-> planar samples (vocoder-audio frames all channels interleaved and splits them
+// per frame, Audio.hs:51-55; here the split happens once for the whole buffer).
+__global__ void deinterleave_kernel(const double *__restrict__ inter, long long n, int channels,
+                                    double *__restrict__ planar, long long stride)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        for (int c = 0; c < channels; ++c) planar[c * stride + i] = inter[i * channels + c];
+}
+
+__global__ void interleave_kernel(const double *__restrict__ planar, long long stride, long long n, int channels,
+                                  double *__restrict__ inter)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        for (int c = 0; c < channels; ++c) inter[i * channels + c] = planar[c * stride + i];
+}
+
 // ------------------------------------------------------------------ step-level, framing, overlap-add
 
 // analysisStep over B independent frames (Vocoder.hs:158-163)
