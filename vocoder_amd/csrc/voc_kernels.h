@@ -239,6 +239,28 @@ VOC_DEV int frexp_exponent(double v)  // exponent e with |v| = m 2^e, 0.5 <= m <
 #endif
 }
 
+// sqrt(s) for s = 0 or 0.25 <= s < 2 (a sum of two squares of numbers scaled into [0, 1), the larger
+// one at least 0.5): reciprocal-square-root seed, one coupled Newton step on (sqrt, 1/(2 sqrt)), two
+// residual corrections -- the device library's own sequence without its rescaling of tiny
+// arguments and its special-case tests, neither of which can trigger on this domain.
+VOC_DEV double sqrt_scaled(double s, bool is_zero)
+{
+#ifdef VOC_EMU
+    (void)is_zero;
+    return sqrt(s);
+#else
+    const double y = __builtin_amdgcn_rsq(s);
+    double g = s * y;
+    double h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    g = fma(fma(-g, g, s), h, g);
+    g = fma(fma(-g, g, s), h, g);
+    return is_zero ? 0.0 : g;
+#endif
+}
+
 // One Horner step p*z + c with the coefficient read from a scalar register pair.  Written as an
 // instruction because the compiler otherwise selects the two-address multiply-add, which needs the
 // coefficient copied into a vector register first: one extra instruction per step and a vector
@@ -290,7 +312,8 @@ VOC_DEV void hs_polar(double x, double y, double &mag, double &ph)
     const int e = frexp_exponent(fmax(ax, ay));
     const double sx = ldexp(ax, -e), sy = ldexp(ay, -e);
     const double a = sx * sx, b = sy * sy;
-    mag = ldexp(sqrt(a + b), e);
+    const bool is_zero = ax == 0.0 && ay == 0.0;
+    mag = ldexp(sqrt_scaled(a + b, is_zero), e);
     const double mx = fmax(sx, sy), mn = fmin(sx, sy);
     const bool fold = mn > 0.41421356237309503 * mx;
     const double num = fold ? mn - mx : mn;
@@ -299,7 +322,7 @@ VOC_DEV void hs_polar(double x, double y, double &mag, double &ph)
     t = fold ? t + 0.78539816339744828 : t;
     t = (ay > ax) ? 1.5707963267948966 - t : t;
     t = __builtin_signbit(x) ? kPi - t : t;
-    ph = (ax == 0.0 && ay == 0.0) ? 0.0 : copysign(t, y);
+    ph = is_zero ? 0.0 : copysign(t, y);
 }
 
 VOC_DEV double hs_magnitude(double x, double y)

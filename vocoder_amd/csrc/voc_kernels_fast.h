@@ -142,8 +142,8 @@ VOC_DEV double2 split_tw(double2 s, int m, bool self_pair)
     opaque(s);
     const double cr = m == 0 ? 1.0 : (m == 1 ? 0.92387953251128673848 : (m == 2 ? 0.70710678118654752440 : 0.38268343236508977173));
     const double ci = m == 0 ? 0.0 : (m == 1 ? -0.38268343236508977173 : (m == 2 ? -0.70710678118654752440 : -0.92387953251128673848));
-    const double2 w = cmul(s, make_double2(cr, ci));
-    return self_pair ? make_double2(0.0, -1.0) : (m == 0 ? s : w);
+    const double2 w = cmul(s, make_double2(cr, ci));  // m == 0: s * (1, 0) = s exactly
+    return self_pair ? make_double2(0.0, -1.0) : w;
 }
 
 template <int LOG2M>
