@@ -47,7 +47,14 @@ enum {
     VOC_ERR_NO_DEVICE = -6    /* no usable GPU */
 };
 
-enum { VOC_PRECISION_F64 = 0 };
+/* VOC_PRECISION_F64: the reference's arithmetic; every entry point without `_f32` in its name.
+ * VOC_PRECISION_F32: a reduced-precision variant of the fused path only (voc_roundtrip_f32*):
+ * float samples, STFT and phases, the synthesis phase kept wrapped into [-pi, pi) (an
+ * unwrapped float phase loses all resolution within a few thousand frames).  Its parity bar
+ * is its own (tests/test_f32_cpu.py, tests/test_gpu_f32.py): relative L2 <= 2e-4 on output
+ * samples against the double-precision oracle.  A context serves one precision; entry points
+ * of the other one return VOC_ERR_UNSUPPORTED. */
+enum { VOC_PRECISION_F64 = 0, VOC_PRECISION_F32 = 1 };
 
 const char *voc_strerror(int32_t status);
 /* Text of the last failing HIP call made through this context (empty if none). */
@@ -160,6 +167,18 @@ int32_t voc_roundtrip_dev(voc_ctx *ctx, const double *x, int64_t x_stride, int64
                           int64_t chunk, double *y, int64_t y_stride, double *ana_phase_io, double *syn_phase_io,
                           double *leftover, int64_t leftover_stride, void *workspace, int64_t workspace_bytes,
                           void *stream);
+
+/* ---- fused path, single precision (contexts created with VOC_PRECISION_F32) --------------------
+ * Same contract as voc_roundtrip / voc_roundtrip_dev with float buffers; the phases returned
+ * are wrapped.  voc_roundtrip_workspace_bytes accounts for the context's precision.
+ */
+int32_t voc_roundtrip_f32(voc_ctx *ctx, const float *x, int64_t x_stride, int64_t length, int64_t channels,
+                          int64_t chunk, float *y, int64_t y_stride, float *ana_phase_io, float *syn_phase_io,
+                          float *leftover, int64_t leftover_stride);
+int32_t voc_roundtrip_f32_dev(voc_ctx *ctx, const float *x, int64_t x_stride, int64_t length, int64_t channels,
+                              int64_t chunk, float *y, int64_t y_stride, float *ana_phase_io, float *syn_phase_io,
+                              float *leftover, int64_t leftover_stride, void *workspace, int64_t workspace_bytes,
+                              void *stream);
 
 /* ---- the two halves of the fused path, device pointers ---------------------------------------
  * For callers that put something between analysis and synthesis (a frequency-domain filter,

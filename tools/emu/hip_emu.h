@@ -35,6 +35,12 @@ struct alignas(16) double2 {
     double x, y;
 };
 static inline double2 make_double2(double x, double y) { return double2{x, y}; }
+struct alignas(8) float2 {
+    float x, y;
+};
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+// device code resolves fma(float, float, float) to the single-precision instruction
+static inline float fma(float a, float b, float c) { return std::fmaf(a, b, c); }
 
 namespace emu {
 struct BlockCtx {

@@ -72,6 +72,8 @@ SIGNATURES = {
     "voc_stream_push_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, C.POINTER(_i64), _vp]),
     "voc_stream_flush": (_i32, [_vp, _vp, _i64, _i64, C.POINTER(_i64)]),
     "voc_stream_flush_dev": (_i32, [_vp, _vp, _i64, _i64, C.POINTER(_i64), _vp]),
+    "voc_roundtrip_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64]),
+    "voc_roundtrip_f32_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
     "voc_profile_enable": (_i32, [_vp, _i32]),
     "voc_profile_read": (_i32, [_vp, _vp, _vp]),
     "voc_roundtrip_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),

@@ -62,12 +62,14 @@ def sum_frames_e(par: VocoderParams, frames, chunk: int | None = None):
 def process_with(par: VocoderParams, x, leftover=None, phases=None, chunk: int | None = None):
     """One `processWith q phs idFilter` step (Conduit.hs:53): returns (y, leftover', (ana_ph', syn_ph')).
     x: (L,) or (C, L) new samples; leftover: (.., r) samples kept from the previous call."""
-    x = _f64(x)
+    f32 = getattr(par, "precision", "f64") == "f32"
+    dt = np.float32 if f32 else np.float64
+    x = np.ascontiguousarray(x, dtype=dt)
     multi = x.ndim == 2
     x2 = x if multi else x[None]
     c = x2.shape[0]
     if leftover is not None and np.size(leftover):
-        x2 = np.concatenate([_f64(leftover).reshape(c, -1), x2], axis=1)
+        x2 = np.concatenate([np.asarray(leftover, dtype=dt).reshape(c, -1), x2], axis=1)
     x2 = np.ascontiguousarray(x2)
     length = x2.shape[1]
     chunk = par.H if chunk is None else chunk
@@ -75,13 +77,13 @@ def process_with(par: VocoderParams, x, leftover=None, phases=None, chunk: int |
     n = ola_length(par, f, chunk)
     keep = leftover_length(par, length)
     if phases is None:
-        aph, sph = zero_phase(par, c), zero_phase(par, c)
+        aph, sph = zero_phase(par, c).astype(dt), zero_phase(par, c).astype(dt)
     else:
-        aph = np.array(phases[0], dtype=np.float64, copy=True).reshape(c, par.K)
-        sph = np.array(phases[1], dtype=np.float64, copy=True).reshape(c, par.K)
-    y = np.empty((c, n))
-    left = np.empty((c, keep))
-    par._call("voc_roundtrip", _p(x2), length, length, c, chunk, _p(y), n, _p(aph), _p(sph), _p(left), keep)
+        aph = np.array(phases[0], dtype=dt, copy=True).reshape(c, par.K)
+        sph = np.array(phases[1], dtype=dt, copy=True).reshape(c, par.K)
+    y = np.empty((c, n), dtype=dt)
+    left = np.empty((c, keep), dtype=dt)
+    par._call("voc_roundtrip_f32" if f32 else "voc_roundtrip", _p(x2), length, length, c, chunk, _p(y), n, _p(aph), _p(sph), _p(left), keep)
     if not multi:
         return y[0], left[0], (aph[0], sph[0])
     return y, left, (aph, sph)
@@ -103,7 +105,9 @@ def process_dev(par: VocoderParams, x, y, ana_phase, syn_phase, length: int | No
     (default: torch's current stream) and returns without synchronising."""
     import torch
 
-    assert x.is_cuda and y.is_cuda and x.dtype == torch.float64 and y.dtype == torch.float64
+    f32 = getattr(par, "precision", "f64") == "f32"
+    dt = torch.float32 if f32 else torch.float64
+    assert x.is_cuda and y.is_cuda and x.dtype == dt and y.dtype == dt
     assert x.stride(-1) == 1 and y.stride(-1) == 1 and ana_phase.is_contiguous() and syn_phase.is_contiguous()
     c = x.shape[0]
     length = x.shape[1] if length is None else length
@@ -111,7 +115,7 @@ def process_dev(par: VocoderParams, x, y, ana_phase, syn_phase, length: int | No
     st = torch.cuda.current_stream(x.device).cuda_stream if stream is None else stream
     lp, ls = (None, 0) if leftover is None else (C.c_void_p(leftover.data_ptr()), leftover.stride(0))
     wp, wb = (None, 0) if workspace is None else (C.c_void_p(workspace.data_ptr()), workspace.numel() * workspace.element_size())
-    par._call("voc_roundtrip_dev", C.c_void_p(x.data_ptr()), x.stride(0), length, c, chunk,
+    par._call("voc_roundtrip_f32_dev" if f32 else "voc_roundtrip_dev", C.c_void_p(x.data_ptr()), x.stride(0), length, c, chunk,
               C.c_void_p(y.data_ptr()), y.stride(0), C.c_void_p(ana_phase.data_ptr()),
               C.c_void_p(syn_phase.data_ptr()), lp, ls, wp, wb, C.c_void_p(st))
 

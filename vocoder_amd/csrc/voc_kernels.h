@@ -33,16 +33,28 @@ constexpr double kTwoPi = 2.0 * kPi;
 constexpr double kInvTwoPi = 0.15915494309189533576888376337251436;
 constexpr double kSqrtHalf = 0.70710678118654752440084436210484904;
 
-struct Params {
+// The kernels of this file exist in two precisions: R = double (the reference's arithmetic, bit
+// for bit where the reference fixes it) and R = float (a reduced-precision variant with its own,
+// looser, parity bar).  cplx<R> is the matching two-component vector type.
+template <class R> struct CplxOf;
+template <> struct CplxOf<double> { using type = double2; };
+template <> struct CplxOf<float> { using type = float2; };
+template <class R> using cplx = typename CplxOf<R>::type;
+VOC_DEV double2 mk2(double x, double y) { return make_double2(x, y); }
+VOC_DEV float2 mk2(float x, float y) { return make_float2(x, y); }
+
+template <class R>
+struct ParamsT {
     int N, W, H, K, M;
     int hd;        // zeros addZeroPadding puts in front: diff - diff div 2        (Vocoder.hs:138)
     int off;       // cutCenter offset (N - W) div 2                               (Vocoder.hs:200)
     int hop_pow2;  // H is a power of two: x / H == x * (1/H) exactly
-    double hop_d, inv_hop, inv_n;
-    const double *window;  // [W]
-    const double2 *twP;    // [M-1]    per-pass twiddles, see fft_passes
-    const double2 *twS;    // [M/2+1]  exp(-2 pi i k / N)
+    R hop_d, inv_hop, inv_n;
+    const R *window;       // [W]
+    const cplx<R> *twP;    // [M-1]    per-pass twiddles, see fft_passes
+    const cplx<R> *twS;    // [M/2+1]  exp(-2 pi i k / N)
 };
+using Params = ParamsT<double>;
 
 template <int LOG2M>
 struct Cfg {
@@ -54,58 +66,54 @@ struct Cfg {
 };
 
 // ------------------------------------------------------------------ complex helpers
-VOC_DEV double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
-VOC_DEV double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
-VOC_DEV double2 cmul(double2 a, double2 b)
+template <class C> VOC_DEV C cadd(C a, C b) { return mk2(a.x + b.x, a.y + b.y); }
+template <class C> VOC_DEV C csub(C a, C b) { return mk2(a.x - b.x, a.y - b.y); }
+template <class C> VOC_DEV C cmul(C a, C b)
 {
-    return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x));
+    return mk2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x));
 }
-VOC_DEV double2 cmul_conj(double2 a, double2 b)  // a * conj(b)
+template <class C> VOC_DEV C cmul_conj(C a, C b)  // a * conj(b)
 {
-    return make_double2(fma(a.x, b.x, a.y * b.y), fma(a.y, b.x, -(a.x * b.y)));
+    return mk2(fma(a.x, b.x, a.y * b.y), fma(a.y, b.x, -(a.x * b.y)));
 }
-VOC_DEV double2 mul_mi(double2 a) { return make_double2(a.y, -a.x); }  // a * (-i)
-VOC_DEV double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
+template <class C> VOC_DEV C mul_mi(C a) { return mk2(a.y, -a.x); }  // a * (-i)
+template <class C> VOC_DEV C cconj(C a) { return mk2(a.x, -a.y); }
 VOC_DEV int lds_pad(int i) { return i + (i >> 3); }
 
-VOC_DEV void bf2(double2 &a, double2 &b)
+template <class C> VOC_DEV void bf2(C &a, C &b)
 {
-    double2 t = a;
+    C t = a;
     a = cadd(t, b);
     b = csub(t, b);
 }
 
 // Forward DFT of RAD points in place, natural order in and out.
-template <int RAD>
-VOC_DEV void dft(double2 (&v)[RAD]);
+template <class C> VOC_DEV void dft_n(C (&v)[2]) { bf2(v[0], v[1]); }
 
-template <>
-VOC_DEV void dft<2>(double2 (&v)[2]) { bf2(v[0], v[1]); }
-
-template <>
-VOC_DEV void dft<4>(double2 (&v)[4])
+template <class C> VOC_DEV void dft_n(C (&v)[4])
 {
     bf2(v[0], v[2]);
     bf2(v[1], v[3]);
     v[3] = mul_mi(v[3]);
     bf2(v[0], v[1]);
     bf2(v[2], v[3]);
-    double2 t = v[1];  // bit-reversed -> natural
+    C t = v[1];  // bit-reversed -> natural
     v[1] = v[2];
     v[2] = t;
 }
 
-template <>
-VOC_DEV void dft<8>(double2 (&v)[8])
+template <class C> VOC_DEV void dft_n(C (&v)[8])
 {
+    using R = decltype(v[0].x);
+    const R kh = (R)kSqrtHalf;
     bf2(v[0], v[4]);
     bf2(v[1], v[5]);
     bf2(v[2], v[6]);
     bf2(v[3], v[7]);
     // twiddles W8^1, W8^2, W8^3 on the lower half
-    v[5] = make_double2((v[5].x + v[5].y) * kSqrtHalf, (v[5].y - v[5].x) * kSqrtHalf);
+    v[5] = mk2((v[5].x + v[5].y) * kh, (v[5].y - v[5].x) * kh);
     v[6] = mul_mi(v[6]);
-    v[7] = make_double2((v[7].y - v[7].x) * kSqrtHalf, -((v[7].x + v[7].y) * kSqrtHalf));
+    v[7] = mk2((v[7].y - v[7].x) * kh, -((v[7].x + v[7].y) * kh));
     bf2(v[0], v[2]);
     bf2(v[1], v[3]);
     v[3] = mul_mi(v[3]);
@@ -117,10 +125,12 @@ VOC_DEV void dft<8>(double2 (&v)[8])
     bf2(v[4], v[5]);
     bf2(v[6], v[7]);
     // registers now hold y0 y4 y2 y6 y1 y5 y3 y7
-    double2 t;
+    C t;
     t = v[1]; v[1] = v[4]; v[4] = t;
     t = v[3]; v[3] = v[6]; v[6] = t;
 }
+
+template <int RAD, class C> VOC_DEV void dft(C (&v)[RAD]) { dft_n(v); }
 
 // One Stockham pass of radix RAD at stride NS over M points.  Butterfly i reads
 // in[i + j*M/RAD], multiplies by exp(-2 pi i j k / (NS*RAD)) with k = i mod NS, and
@@ -134,15 +144,15 @@ VOC_DEV void dft<8>(double2 (&v)[8])
 // LDS: element e lives at e + e/8 (one 16-byte pad per 8 elements keeps the stride-8 stores
 // of the first pass off a single bank); when a stride is a multiple of 8 the padded index
 // is linear in j, which the code spells out so that the j-th access is base + constant.
-template <int M, int T, int NS, class Loader>
-VOC_DEV void fft_passes(double2 *lds, const double2 *__restrict__ twP, int tid, Loader ld)
+template <int M, int T, int NS, class C, class Loader>
+VOC_DEV void fft_passes(C *lds, const C *__restrict__ twP, int tid, Loader ld)
 {
     constexpr int REM = M / NS;
     constexpr int RAD = REM >= 8 ? 8 : REM;
     constexpr int NBF = M / RAD;
     constexpr int NB = (NBF + T - 1) / T;
     constexpr bool LIN_ST = (NS % 8 == 0) || (NS == 1 && RAD == 8);
-    double2 v[NB][RAD];
+    C v[NB][RAD];
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
         const int i = tid + q * T;
@@ -153,7 +163,7 @@ VOC_DEV void fft_passes(double2 *lds, const double2 *__restrict__ twP, int tid, 
                 const unsigned k = (unsigned)i & (unsigned)(NS - 1);
 #pragma unroll
                 for (int j = 1; j < RAD; ++j) {
-                    const double2 *tj = twP + (NS - 1) + (j - 1) * NS;  // uniform base of row j
+                    const C *tj = twP + (NS - 1) + (j - 1) * NS;  // uniform base of row j
                     v[q][j] = cmul(v[q][j], tj[k]);
                 }
             }
@@ -168,7 +178,7 @@ VOC_DEV void fft_passes(double2 *lds, const double2 *__restrict__ twP, int tid, 
             const int k = i & (NS - 1);
             const int j0 = (i - k) * RAD + k;
             if (LIN_ST) {
-                double2 *dst = lds + lds_pad(j0);
+                C *dst = lds + lds_pad(j0);
 #pragma unroll
                 for (int j = 0; j < RAD; ++j) dst[j * (NS + NS / 8)] = v[q][j];
             } else {
@@ -188,12 +198,12 @@ VOC_DEV void fft_passes(double2 *lds, const double2 *__restrict__ twP, int tid, 
 }
 
 // first-pass loader over LDS: element i + j*NBF of the M-point array
-template <int M>
+template <int M, class C = double2>
 struct LdsLoader {
-    const double2 *lds;
+    const C *lds;
     static constexpr int RAD0 = M >= 8 ? 8 : M;
     static constexpr int NBF = M / RAD0;
-    VOC_DEV double2 operator()(int i, int j) const
+    VOC_DEV C operator()(int i, int j) const
     {
         if (NBF % 8 == 0) return (lds + lds_pad(i))[j * (NBF + NBF / 8)];
         return lds[lds_pad(i + j * NBF)];
@@ -389,18 +399,59 @@ VOC_DEV double hs_wrap(double e)
     return (n - t) - kPi;
 }
 
+// ---- single precision: the same definitions on float.  magnitude keeps the scaled form, the
+// phase is the device library's atan2f with the reference's 0 for 0:+0, sin / cos are the device
+// library's (accurate for every float), wrap keeps the floored-modulus shape.
+VOC_DEV void hs_polar(float x, float y, float &mag, float &ph)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    int e = 0;
+    const float mx = fmaxf(ax, ay);
+    if (mx != 0.0f) (void)frexpf(mx, &e);
+    const float sx = ldexpf(ax, -e), sy = ldexpf(ay, -e);
+    mag = ldexpf(sqrtf(sx * sx + sy * sy), e);
+    ph = (ax == 0.0f && ay == 0.0f) ? 0.0f : atan2f(y, x);
+}
+
+VOC_DEV void fast_sincos(float x, float *sn, float *cs)
+{
+    *sn = sinf(x);
+    *cs = cosf(x);
+}
+
+VOC_DEV float hs_wrap(float e)
+{
+    const float pi = (float)kPi, two_pi = (float)kTwoPi;
+    const float n = e + pi;
+    const float f0 = floorf(n * (float)kInvTwoPi);
+    const bool below = fmaf(-f0, two_pi, n) < 0.0f;
+    const bool above = fmaf(-(f0 + 1.0f), two_pi, n) >= 0.0f;
+    const float f = below ? f0 - 1.0f : (above ? f0 + 1.0f : f0);
+    return (n - f * two_pi) - pi;
+}
+
 // calcPhaseInc (Vocoder.hs:169-173): omega = ((2 pi k) H) / N ; (omega + wrap (d - omega)) / H
-VOC_DEV double phase_inc(const Params &p, int k, double ph_diff)
+VOC_DEV double phase_inc(const ParamsT<double> &p, int k, double ph_diff)
 {
     const double omega = ((kTwoPi * (double)k) * p.hop_d) * p.inv_n;
     const double s = omega + hs_wrap(ph_diff - omega);
     return p.hop_pow2 ? s * p.inv_hop : s / p.hop_d;
 }
 
-// analysisStep for one bin (Vocoder.hs:158-163).  `prev` is replaced by the new raw phase.
-VOC_DEV void analyze_bin(const Params &p, int k, double2 X, double &prev, bool emit, double vol, double *mag, double *inc)
+// float variant: omega reaches thousands of radians, so the sum is formed in double (a float
+// 2 pi alone would bias every frame's increment by omega * 3e-8) and rounded to float once.
+VOC_DEV float phase_inc(const ParamsT<float> &p, int k, float ph_diff)
 {
-    double m, ph;
+    const double omega = ((kTwoPi * (double)k) * (double)p.hop_d) * (double)p.inv_n;
+    const double s = omega + hs_wrap((double)ph_diff - omega);
+    return (float)(s / (double)p.hop_d);
+}
+
+// analysisStep for one bin (Vocoder.hs:158-163).  `prev` is replaced by the new raw phase.
+template <class R>
+VOC_DEV void analyze_bin(const ParamsT<R> &p, int k, cplx<R> X, R &prev, bool emit, R vol, R *mag, R *inc)
+{
+    R m, ph;
     hs_polar(X.x, X.y, m, ph);
     if (emit) {
         *mag = m * vol;
@@ -409,50 +460,62 @@ VOC_DEV void analyze_bin(const Params &p, int k, double2 X, double &prev, bool e
     prev = ph;
 }
 
-// synthesisStep for one bin (Vocoder.hs:186-190): ph + (ph_inc * H), then mkPolar.
-VOC_DEV double2 synthesize_bin(const Params &p, double mag, double inc, double &ph)
+// The synthesis phase chain, one step (Vocoder.hs:190): ph + (ph_inc * H), two roundings, never
+// wrapped -- in double.  The float variant wraps the sum into [-pi, pi): an unwrapped float phase
+// grows past 2^24 ulp-of-a-radian within a few thousand frames and would lose the phase entirely.
+VOC_DEV double phase_step(double ph, double t) { return ph + t; }
+// (the sum and its wrap are formed in double: t = ph_inc * H reaches thousands of radians, where a
+// float has a resolution of a milliradian)
+VOC_DEV float phase_step(float ph, float t) { return (float)hs_wrap((double)ph + (double)t); }
+
+// synthesisStep for one bin (Vocoder.hs:186-190): the phase step, then mkPolar.
+template <class R>
+VOC_DEV cplx<R> synthesize_bin(const ParamsT<R> &p, R mag, R inc, R &ph)
 {
-    const double t = inc * p.hop_d;
-    ph = ph + t;
-    double s, c;
+    const R t = inc * p.hop_d;
+    ph = phase_step(ph, t);
+    R s, c;
     fast_sincos(ph, &s, &c);
-    return make_double2(mag * c, mag * s);
+    return mk2(mag * c, mag * s);
 }
 
 // ------------------------------------------------------------------ analysis
 
-struct AnaArgs {
-    const double *x;        // frame (c, f) starts at x + c*chan_stride + f*frame_stride
+template <class R>
+struct AnaArgsT {
+    const R *x;             // frame (c, f) starts at x + c*chan_stride + f*frame_stride
     long long chan_stride;  // [C][F][W]: F*W ; raw signal: samples per channel row
     long long frame_stride; // [C][F][W]: W   ; raw signal: H
-    const double *phase_in; // [C][K]
-    double *phase_out;      // [C][K]
-    double *mag, *inc;      // [(c*F + f)*ldk + k]
-    double *spec;           // SPEC_OUT: [(c*F + f)*K + k] complex
+    const R *phase_in;      // [C][K]
+    R *phase_out;           // [C][K]
+    R *mag, *inc;           // [(c*F + f)*ldk + k]
+    R *spec;                // SPEC_OUT: [(c*F + f)*K + k] complex
     long long ldk;
     long long F;
     int tile_len, tiles;
-    double vol;             // factor folded into mag (volumeFix), 1 for the plain stage
+    R vol;                  // factor folded into mag (volumeFix), 1 for the plain stage
 };
+using AnaArgs = AnaArgsT<double>;
 
 // RAW: plain R2C of N contiguous reals (no window / pad / rewind).  SPEC_OUT: write the complex
 // spectrum instead of (mag, ph_inc).
-template <int LOG2M, bool RAW, bool SPEC_OUT>
-__global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) analysis_kernel(Params p, AnaArgs a)
+template <int LOG2M, bool RAW, bool SPEC_OUT, class R = double>
+__global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) analysis_kernel(ParamsT<R> p, AnaArgsT<R> a)
 {
     constexpr int M = Cfg<LOG2M>::M, T = Cfg<LOG2M>::T, NP = Cfg<LOG2M>::NP;
-    VOC_SMEM(double2, lds);
+    using C2 = cplx<R>;
+    VOC_SMEM(C2, lds);
     const int tid = threadIdx.x;
     const long long c = blockIdx.x / a.tiles;
     const int tile = blockIdx.x % a.tiles;
     const long long f0 = (long long)tile * a.tile_len;
     const long long f1 = (f0 + a.tile_len < a.F) ? f0 + a.tile_len : a.F;
-    const double *xc = a.x + c * a.chan_stride;
+    const R *xc = a.x + c * a.chan_stride;
     const bool own_half = (tid == T - 1);  // the thread that also owns bin M/2
 
-    double prev[2 * NP + 1];
+    R prev[2 * NP + 1];
     if (!SPEC_OUT && f0 == 0) {
-        const double *pi = a.phase_in + c * p.K;
+        const R *pi = a.phase_in + c * p.K;
 #pragma unroll
         for (int m = 0; m < NP; ++m) {
             const int pr = tid + m * T;
@@ -466,17 +529,17 @@ __global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) analysis_kernel(Params p, An
 
     const long long fs = (!SPEC_OUT && f0 > 0) ? f0 - 1 : f0;  // one frame early to recover its raw phase
     for (long long f = fs; f < f1; ++f) {
-        const double *fr = xc + f * a.frame_stride;
+        const R *fr = xc + f * a.frame_stride;
         const bool emit = f >= f0;
         // ---- first pass reads straight from global: window, zero pad, rewind, even/odd packing
-        auto loader = [&](int i, int j) -> double2 {
+        auto loader = [&](int i, int j) -> C2 {
             const int m = i + j * (M / (M >= 8 ? 8 : M));
-            if (RAW) return make_double2(fr[2 * m], fr[2 * m + 1]);
+            if (RAW) return mk2(fr[2 * m], fr[2 * m + 1]);
             const int i0 = ((2 * m + M) & (p.N - 1)) - p.hd;       // rewind: v[n] = padded[(n + N/2) mod N]
             const int i1 = ((2 * m + 1 + M) & (p.N - 1)) - p.hd;
-            double2 z;
-            z.x = (i0 >= 0 && i0 < p.W) ? p.window[i0] * fr[i0] : 0.0;
-            z.y = (i1 >= 0 && i1 < p.W) ? p.window[i1] * fr[i1] : 0.0;
+            C2 z;
+            z.x = (i0 >= 0 && i0 < p.W) ? p.window[i0] * fr[i0] : (R)0;
+            z.y = (i1 >= 0 && i1 < p.W) ? p.window[i1] * fr[i1] : (R)0;
             return z;
         };
         fft_passes<M, T, 1>(lds, p.twP, tid, loader);
@@ -486,27 +549,27 @@ __global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) analysis_kernel(Params p, An
         for (int m = 0; m < NP; ++m) {
             const int pr = tid + m * T;
             if (pr < M / 2) {
-                double2 Xa, Xb;  // bins pr and M - pr
+                C2 Xa, Xb;  // bins pr and M - pr
                 if (pr == 0) {
-                    const double2 z0 = lds[lds_pad(0)];
-                    Xa = make_double2(z0.x + z0.y, 0.0);
-                    Xb = make_double2(z0.x - z0.y, 0.0);
+                    const C2 z0 = lds[lds_pad(0)];
+                    Xa = mk2(z0.x + z0.y, (R)0);
+                    Xb = mk2(z0.x - z0.y, (R)0);
                 } else {
-                    const double2 P = lds[lds_pad(pr)], Q = lds[lds_pad(M - pr)];
-                    const double2 E = make_double2(0.5 * (P.x + Q.x), 0.5 * (P.y - Q.y));
-                    const double2 O = make_double2(0.5 * (P.y + Q.y), 0.5 * (Q.x - P.x));  // (P - conj Q) / (2i)
-                    const double2 U = cmul(p.twS[pr], O);
+                    const C2 P = lds[lds_pad(pr)], Q = lds[lds_pad(M - pr)];
+                    const C2 E = mk2((R)0.5 * (P.x + Q.x), (R)0.5 * (P.y - Q.y));
+                    const C2 O = mk2((R)0.5 * (P.y + Q.y), (R)0.5 * (Q.x - P.x));  // (P - conj Q) / (2i)
+                    const C2 U = cmul(p.twS[pr], O);
                     Xa = cadd(E, U);
                     Xb = cconj(csub(E, U));
                 }
                 if (SPEC_OUT) {
-                    double *s = a.spec + row * 2 * p.K;
+                    R *s = a.spec + row * 2 * p.K;
                     s[2 * pr] = Xa.x;
                     s[2 * pr + 1] = Xa.y;
                     s[2 * (M - pr)] = Xb.x;
                     s[2 * (M - pr) + 1] = Xb.y;
                 } else {
-                    double mg, ic;
+                    R mg, ic;
                     analyze_bin(p, pr, Xa, prev[2 * m], emit, a.vol, &mg, &ic);
                     if (emit) {
                         a.mag[row * a.ldk + pr] = mg;
@@ -521,13 +584,13 @@ __global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) analysis_kernel(Params p, An
             }
         }
         if (own_half) {
-            const double2 X = cconj(lds[lds_pad(M / 2)]);  // W^(M/2) = -i
+            const C2 X = cconj(lds[lds_pad(M / 2)]);  // W^(M/2) = -i
             if (SPEC_OUT) {
-                double *s = a.spec + row * 2 * p.K;
+                R *s = a.spec + row * 2 * p.K;
                 s[M] = X.x;
                 s[M + 1] = X.y;
             } else {
-                double mg, ic;
+                R mg, ic;
                 analyze_bin(p, M / 2, X, prev[2 * NP], emit, a.vol, &mg, &ic);
                 if (emit) {
                     a.mag[row * a.ldk + M / 2] = mg;
@@ -539,7 +602,7 @@ __global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) analysis_kernel(Params p, An
     }
 
     if (!SPEC_OUT && f1 == a.F && f1 > f0) {
-        double *po = a.phase_out + c * p.K;
+        R *po = a.phase_out + c * p.K;
 #pragma unroll
         for (int m = 0; m < NP; ++m) {
             const int pr = tid + m * T;
@@ -557,26 +620,29 @@ __global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) analysis_kernel(Params p, An
 enum { SYN_IN_POLAR = 0, SYN_IN_SPEC = 1 };
 enum { SYN_OUT_FRAMES = 0, SYN_OUT_RAW = 1, SYN_OUT_OLA = 2 };
 
-struct SynArgs {
-    const double *mag, *inc;  // [(c*F + f)*ldk + k]
+template <class R>
+struct SynArgsT {
+    const R *mag, *inc;       // [(c*F + f)*ldk + k]
     long long ldk;
-    const double *spec;       // IN_SPEC: [(c*F + f)*K + k] complex
-    const double *phase_in;   // [C][K]           chain start of tile 0
-    const double *carry;      // [C][tiles][K]    chain start of tiles > 0
-    double *phase_out;        // [C][K]
-    double *out;              // FRAMES: [(c*F + f)*W + i]; RAW: [(c*F + f)*N + n]; OLA: [c*out_stride + s]
+    const R *spec;            // IN_SPEC: [(c*F + f)*K + k] complex
+    const R *phase_in;        // [C][K]           chain start of tile 0
+    const R *carry;           // [C][tiles][K]    chain start of tiles > 0
+    R *phase_out;             // [C][K]
+    R *out;                   // FRAMES: [(c*F + f)*W + i]; RAW: [(c*F + f)*N + n]; OLA: [c*out_stride + s]
     long long out_stride;
     long long out_len;        // OLA: samples per channel, last chunk zero padded
     long long F;
     int tile_len, tiles, halo;
 };
+using SynArgs = SynArgsT<double>;
 
-template <int LOG2M, int IN_MODE, int OUT_MODE>
-__global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) synthesis_kernel(Params p, SynArgs a)
+template <int LOG2M, int IN_MODE, int OUT_MODE, class R = double>
+__global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) synthesis_kernel(ParamsT<R> p, SynArgsT<R> a)
 {
     constexpr int M = Cfg<LOG2M>::M, T = Cfg<LOG2M>::T, NP = Cfg<LOG2M>::NP, NQ = Cfg<LOG2M>::NQ;
-    VOC_SMEM(double2, lds);
-    double *ring = reinterpret_cast<double *>(lds + Cfg<LOG2M>::LDS_CPLX);  // OLA partial sums, W doubles
+    using C2 = cplx<R>;
+    VOC_SMEM(C2, lds);
+    R *ring = reinterpret_cast<R *>(lds + Cfg<LOG2M>::LDS_CPLX);  // OLA partial sums, W values
     const int tid = threadIdx.x;
     const long long c = blockIdx.x / a.tiles;
     const int tile = blockIdx.x % a.tiles;
@@ -588,9 +654,9 @@ __global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) synthesis_kernel(Params p, S
     const long long halo = (OUT_MODE == SYN_OUT_OLA) ? ((long long)a.halo < f0 ? (long long)a.halo : f0) : 0;
     const long long fs = f0 - halo;
 
-    double ph[2 * NP + 1];
+    R ph[2 * NP + 1];
     if (IN_MODE == SYN_IN_POLAR) {
-        const double *pi = (tile == 0) ? a.phase_in + c * p.K : a.carry + (c * a.tiles + tile) * p.K;
+        const R *pi = (tile == 0) ? a.phase_in + c * p.K : a.carry + (c * a.tiles + tile) * p.K;
 #pragma unroll
         for (int m = 0; m < NP; ++m) {
             const int pr = tid + m * T;
@@ -603,7 +669,7 @@ __global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) synthesis_kernel(Params p, S
     }
     int base = 0;
     if (OUT_MODE == SYN_OUT_OLA) {
-        for (int i = tid; i < p.W; i += T) ring[i] = 0.0;
+        for (int i = tid; i < p.W; i += T) ring[i] = (R)0;
     }
 
     for (long long f = fs; f < f1; ++f) {
@@ -614,47 +680,47 @@ __global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) synthesis_kernel(Params p, S
         for (int m = 0; m < NP; ++m) {
             const int pr = tid + m * T;
             if (pr < M / 2) {
-                double2 A, B;  // X[pr], X[M - pr]
+                C2 A, B;  // X[pr], X[M - pr]
                 if (IN_MODE == SYN_IN_POLAR) {
                     A = synthesize_bin(p, a.mag[row * a.ldk + pr], a.inc[row * a.ldk + pr], ph[2 * m]);
                     B = synthesize_bin(p, a.mag[row * a.ldk + (M - pr)], a.inc[row * a.ldk + (M - pr)], ph[2 * m + 1]);
                 } else {
-                    const double *s = a.spec + row * 2 * p.K;
-                    A = make_double2(s[2 * pr], s[2 * pr + 1]);
-                    B = make_double2(s[2 * (M - pr)], s[2 * (M - pr) + 1]);
+                    const R *s = a.spec + row * 2 * p.K;
+                    A = mk2(s[2 * pr], s[2 * pr + 1]);
+                    B = mk2(s[2 * (M - pr)], s[2 * (M - pr) + 1]);
                 }
                 if (pr == 0) {  // DC and Nyquist: imaginary parts ignored
-                    lds[lds_pad(0)] = make_double2(A.x - B.x, A.x + B.x);  // swapped (im, re)
+                    lds[lds_pad(0)] = mk2(A.x - B.x, A.x + B.x);  // swapped (im, re)
                 } else {
-                    const double2 S = make_double2(A.x + B.x, A.y - B.y);   // A + conj B
-                    const double2 D = make_double2(A.x - B.x, A.y + B.y);   // A - conj B
-                    const double2 Tw = cmul_conj(D, p.twS[pr]);             // W^(-k) D
+                    const C2 S = mk2(A.x + B.x, A.y - B.y);   // A + conj B
+                    const C2 D = mk2(A.x - B.x, A.y + B.y);   // A - conj B
+                    const C2 Tw = cmul_conj(D, p.twS[pr]);             // W^(-k) D
                     // Z[k] = S + i Tw ; Z[M-k] = conj S + i conj Tw
-                    lds[lds_pad(pr)] = make_double2(S.y + Tw.x, S.x - Tw.y);
-                    lds[lds_pad(M - pr)] = make_double2(Tw.x - S.y, S.x + Tw.y);
+                    lds[lds_pad(pr)] = mk2(S.y + Tw.x, S.x - Tw.y);
+                    lds[lds_pad(M - pr)] = mk2(Tw.x - S.y, S.x + Tw.y);
                 }
             }
         }
         if (own_half) {
-            double2 A;
+            C2 A;
             if (IN_MODE == SYN_IN_POLAR) {
                 A = synthesize_bin(p, a.mag[row * a.ldk + M / 2], a.inc[row * a.ldk + M / 2], ph[2 * NP]);
             } else {
-                const double *s = a.spec + row * 2 * p.K;
-                A = make_double2(s[M], s[M + 1]);
+                const R *s = a.spec + row * 2 * p.K;
+                A = mk2(s[M], s[M + 1]);
             }
-            lds[lds_pad(M / 2)] = make_double2(-2.0 * A.y, 2.0 * A.x);  // Z = 2 conj A, swapped
+            lds[lds_pad(M / 2)] = mk2((R)-2 * A.y, (R)2 * A.x);  // Z = 2 conj A, swapped
         }
         __syncthreads();
-        fft_passes<M, T, 1>(lds, p.twP, tid, LdsLoader<M>{lds});
+        fft_passes<M, T, 1>(lds, p.twP, tid, LdsLoader<M, C2>{lds});
         // ---- lds[pad(m)] = swapped z[m]: v[2m] = z.y / N, v[2m+1] = z.x / N  (C2R scaled by 1/N)
         const bool emit = f >= f0;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int m = tid + q * T;
             if (m < M) {
-                const double2 z = lds[lds_pad(m)];
-                const double v0 = z.y * p.inv_n, v1 = z.x * p.inv_n;
+                const C2 z = lds[lds_pad(m)];
+                const R v0 = z.y * p.inv_n, v1 = z.x * p.inv_n;
                 if (OUT_MODE == SYN_OUT_RAW) {
                     a.out[row * p.N + 2 * m] = v0;
                     a.out[row * p.N + 2 * m + 1] = v1;
@@ -683,14 +749,14 @@ __global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) synthesis_kernel(Params p, S
         __syncthreads();
         if (OUT_MODE == SYN_OUT_OLA) {
             // the first H samples of the ring are complete: emit (if owned) and retire them
-            double *yc = a.out + c * a.out_stride;
+            R *yc = a.out + c * a.out_stride;
             for (int i = tid; i < p.H; i += T) {
-                double s = 0.0;
+                R s = (R)0;
                 if (i < p.W) {
                     int r = base + i;
                     if (r >= p.W) r -= p.W;
                     s = ring[r];
-                    ring[r] = 0.0;
+                    ring[r] = (R)0;
                 }
                 const long long pos = f * p.H + i;
                 if (emit && pos < a.out_len) yc[pos] = s;
@@ -703,7 +769,7 @@ __global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) synthesis_kernel(Params p, S
 
     if (f1 == a.F && f1 > f0) {
         if (IN_MODE == SYN_IN_POLAR) {
-            double *po = a.phase_out + c * p.K;
+            R *po = a.phase_out + c * p.K;
 #pragma unroll
             for (int m = 0; m < NP; ++m) {
                 const int pr = tid + m * T;
@@ -718,10 +784,10 @@ __global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) synthesis_kernel(Params p, S
             // tail after the last frame: the ring's remaining W - H partial sums, then zeros up to
             // the end of the last chunk (sumFramesE pads it: Frames.hs:45-47)
             __syncthreads();
-            double *yc = a.out + c * a.out_stride;
+            R *yc = a.out + c * a.out_stride;
             const long long start = a.F * p.H;
             for (long long i = tid; start + i < a.out_len; i += T) {
-                double s = 0.0;
+                R s = (R)0;
                 if (i < p.W - p.H) {
                     int r = base + (int)i;
                     if (r >= p.W) r -= p.W;
@@ -736,28 +802,29 @@ __global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) synthesis_kernel(Params p, S
 // Sequential phase chain per (channel, bin): ph <- ph + ph_inc * H frame after frame
 // (synthesisStep, Vocoder.hs:190), recording the chain value each synthesis tile starts from.
 // Tile t >= 1 starts computing at frame t*tile_len - halo.
-__global__ void phase_carry_kernel(Params p, const double *__restrict__ inc, long long ldk, long long F,
-                                   const double *__restrict__ phase_in, double *__restrict__ carry, int tile_len,
+template <class R>
+__global__ void phase_carry_kernel(ParamsT<R> p, const R *__restrict__ inc, long long ldk, long long F,
+                                   const R *__restrict__ phase_in, R *__restrict__ carry, int tile_len,
                                    int tiles, int halo, long long channels)
 {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= channels * p.K) return;
     const long long c = g / p.K;
     const int k = (int)(g % p.K);
-    double ph = phase_in[c * p.K + k];
-    const double *src = inc + c * F * ldk + k;
+    R ph = phase_in[c * p.K + k];
+    const R *src = inc + c * F * ldk + k;
     long long next = (long long)tile_len - halo;  // frame count after which tile 1 starts
     int t = 1;
     long long f = 0;
     // sixteen loads in flight per thread (the chain is latency bound when there are few channels);
     // the additions stay in frame order
     for (; f + 16 <= F && t < tiles; f += 16) {
-        double dd[16];
+        R dd[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) dd[u] = src[(f + u) * ldk];
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            ph = ph + dd[u] * p.hop_d;
+            ph = phase_step(ph, dd[u] * p.hop_d);
             if (f + u + 1 == next) {
                 if (t < tiles) carry[(c * tiles + t) * p.K + k] = ph;
                 ++t;
@@ -766,8 +833,8 @@ __global__ void phase_carry_kernel(Params p, const double *__restrict__ inc, lon
         }
     }
     for (; f < F && t < tiles; ++f) {
-        const double d = src[f * ldk] * p.hop_d;
-        ph = ph + d;
+        const R d = src[f * ldk] * p.hop_d;
+        ph = phase_step(ph, d);
         if (f + 1 == next) {
             carry[(c * tiles + t) * p.K + k] = ph;
             ++t;
@@ -834,7 +901,7 @@ __global__ void analysis_step_kernel(Params p, const double *prev_ph, const doub
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
         const int k = (int)(g % p.K);
         double prev = prev_ph[g], mg, ic;
-        analyze_bin(p, k, make_double2(spec[2 * g], spec[2 * g + 1]), prev, true, 1.0, &mg, &ic);
+        analyze_bin<double>(p, k, make_double2(spec[2 * g], spec[2 * g + 1]), prev, true, 1.0, &mg, &ic);
         mag[g] = mg;
         inc[g] = ic;
         ph_out[g] = prev;
@@ -882,7 +949,8 @@ __global__ void frames_of_kernel(const double *x, long long x_stride, double *fr
 
 // sumFramesE: y[s] = sum over frames j covering s of frame_j[s - j*H], oldest frame first, folded
 // from 0 (Frames.hs:44-45); samples past the last frame's end are the zero padding of the last chunk.
-__global__ void sum_frames_kernel(const double *frames, long long F, int W, int H, double *y, long long y_stride,
+template <class R>
+__global__ void sum_frames_kernel(const R *frames, long long F, int W, int H, R *y, long long y_stride,
                                   long long out_len, long long total)
 {
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
@@ -891,7 +959,7 @@ __global__ void sum_frames_kernel(const double *frames, long long F, int W, int 
         if (s - W + 1 <= 0) jlo = 0;
         long long jhi = s / H;
         if (jhi > F - 1) jhi = F - 1;
-        double acc = 0.0;
+        R acc = (R)0;
         for (long long j = jlo; j <= jhi; ++j) acc = acc + frames[(c * F + j) * W + (s - j * H)];
         y[c * y_stride + s] = acc;
     }

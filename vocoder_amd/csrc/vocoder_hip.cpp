@@ -12,6 +12,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/vocoder_hip.h"
@@ -28,6 +29,11 @@ struct voc_ctx {
     double *d_window = nullptr;
     double2 *d_twP = nullptr, *d_twS = nullptr;
     voc::Params params{};
+    int precision = VOC_PRECISION_F64;
+    // single-precision contexts: float copies of the tables (the double ones stay for the accessors)
+    float *d_window_f = nullptr;
+    float2 *d_twP_f = nullptr, *d_twS_f = nullptr;
+    voc::ParamsT<float> params_f{};
     void *ws = nullptr;
     size_t ws_bytes = 0;
     int ana_tile_override = 0, syn_tile_override = 0;
@@ -48,6 +54,10 @@ struct HipFail {
     const char *what;
 };
 
+struct StatusFail {  // a plain status code raised below the C boundary
+    int32_t status;
+};
+
 #define HIPCHK(call)                          \
     do {                                      \
         hipError_t e_ = (call);               \
@@ -63,6 +73,8 @@ int32_t guarded(voc_ctx *ctx, Body body)
     } catch (const HipFail &f) {
         if (ctx) ctx->hip_err = std::string(f.what) + ": " + hipGetErrorString(f.e);
         return f.e == hipErrorOutOfMemory ? VOC_ERR_NOMEM : VOC_ERR_HIP;
+    } catch (const StatusFail &f) {
+        return f.status;
     } catch (const std::bad_alloc &) {
         return VOC_ERR_NOMEM;
     } catch (...) {
@@ -115,17 +127,22 @@ inline int env_int(const char *name)
     return s ? std::atoi(s) : 0;
 }
 
+template <class R = double>
 inline size_t lds_bytes(const voc_ctx *c, bool ola)
 {
-    size_t b = (size_t)(c->M + (c->M >> 3) + 2) * sizeof(double2);
-    if (ola) b += (size_t)c->W * sizeof(double);
+    size_t b = (size_t)(c->M + (c->M >> 3) + 2) * 2 * sizeof(R);
+    if (ola) b += (size_t)c->W * sizeof(R);
     return b;
 }
 
+template <class R> const voc::ParamsT<R> &params_of(const voc_ctx *c);
+template <> const voc::ParamsT<double> &params_of<double>(const voc_ctx *c) { return c->params; }
+template <> const voc::ParamsT<float> &params_of<float>(const voc_ctx *c) { return c->params_f; }
+
 #define VOC_FOR_EACH_LOG2M(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
 
-template <bool RAW, bool SPEC>
-void launch_analysis(voc_ctx *c, const voc::AnaArgs &a, long long channels, hipStream_t st)
+template <bool RAW, bool SPEC, class R = double>
+void launch_analysis(voc_ctx *c, const voc::AnaArgsT<R> &a, long long channels, hipStream_t st)
 {
     const long long grid = channels * a.tiles;
     if (grid <= 0) return;
@@ -134,8 +151,8 @@ void launch_analysis(voc_ctx *c, const voc::AnaArgs &a, long long channels, hipS
     switch (c->log2m) {
 #define X(L)                                                                                              \
     case L:                                                                                               \
-        hipLaunchKernelGGL((voc::analysis_kernel<L, RAW, SPEC>), dim3((unsigned)grid), dim3(voc::Cfg<L>::T), \
-                           lds_bytes(c, false), st, c->params, a);                                        \
+        hipLaunchKernelGGL((voc::analysis_kernel<L, RAW, SPEC, R>), dim3((unsigned)grid), dim3(voc::Cfg<L>::T), \
+                           lds_bytes<R>(c, false), st, params_of<R>(c), a);                               \
         break;
         VOC_FOR_EACH_LOG2M(X)
 #undef X
@@ -143,8 +160,8 @@ void launch_analysis(voc_ctx *c, const voc::AnaArgs &a, long long channels, hipS
     HIPCHK(hipGetLastError());
 }
 
-template <int IN_MODE, int OUT_MODE>
-void launch_synthesis(voc_ctx *c, const voc::SynArgs &a, long long channels, hipStream_t st)
+template <int IN_MODE, int OUT_MODE, class R = double>
+void launch_synthesis(voc_ctx *c, const voc::SynArgsT<R> &a, long long channels, hipStream_t st)
 {
     const long long grid = channels * a.tiles;
     if (grid <= 0) return;
@@ -153,8 +170,8 @@ void launch_synthesis(voc_ctx *c, const voc::SynArgs &a, long long channels, hip
     switch (c->log2m) {
 #define X(L)                                                                                                    \
     case L:                                                                                                     \
-        hipLaunchKernelGGL((voc::synthesis_kernel<L, IN_MODE, OUT_MODE>), dim3((unsigned)grid), dim3(voc::Cfg<L>::T), \
-                           lds_bytes(c, OUT_MODE == voc::SYN_OUT_OLA), st, c->params, a);                       \
+        hipLaunchKernelGGL((voc::synthesis_kernel<L, IN_MODE, OUT_MODE, R>), dim3((unsigned)grid), dim3(voc::Cfg<L>::T), \
+                           lds_bytes<R>(c, OUT_MODE == voc::SYN_OUT_OLA), st, params_of<R>(c), a);                 \
         break;
         VOC_FOR_EACH_LOG2M(X)
 #undef X
@@ -367,7 +384,7 @@ void synthesis_stage_dev(voc_ctx *c, double *phase_io, const double *mag, const 
     if (tiles > 1) {
         const long long chains = C * c->K;
         LaunchTimer timer(c, KIND_CARRY, st);
-        hipLaunchKernelGGL(voc::phase_carry_kernel, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL(voc::phase_carry_kernel<double>, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st,
                            c->params, inc, (long long)c->K, F, pin, carry, tile_len, tiles, 0, C);
         HIPCHK(hipGetLastError());
     }
@@ -433,7 +450,7 @@ void synthesis_signal_dev(voc_ctx *c, const double *mag, const double *inc, long
     if (tiles > 1) {
         const long long chains = C * c->K;
         LaunchTimer timer(c, KIND_CARRY, st);
-        hipLaunchKernelGGL(voc::phase_carry_kernel, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, c->params,
+        hipLaunchKernelGGL(voc::phase_carry_kernel<double>, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, c->params,
                            inc, ldk, F, pin, carry, tile_len, tiles, halo, C);
         HIPCHK(hipGetLastError());
     }
@@ -457,7 +474,7 @@ void synthesis_signal_dev(voc_ctx *c, const double *mag, const double *inc, long
         s.out = frames;
         if (!launch_synthesis_fast(c, s, C, false, st)) launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_FRAMES>(c, s, C, st);
         const long long total = C * y_len;
-        hipLaunchKernelGGL(voc::sum_frames_kernel, dim3(ew_grid(total)), dim3(256), 0, st, frames, F, c->W, c->H, y,
+        hipLaunchKernelGGL(voc::sum_frames_kernel<double>, dim3(ew_grid(total)), dim3(256), 0, st, frames, F, c->W, c->H, y,
                            y_stride, y_len, total);
         HIPCHK(hipGetLastError());
     }
@@ -487,7 +504,8 @@ RtPlan roundtrip_plan(const voc_ctx *c, long long len, long long group, long lon
     r.F = num_frames(c, len);
     r.out_len = ola_length(c, r.F, chunk > 0 ? chunk : c->H);
     r.ldk = (c->K + 1) & ~1LL;
-    r.fused_ola = lds_bytes(c, true) <= kLdsLimit;
+    const bool f32 = c->precision == VOC_PRECISION_F32;
+    r.fused_ola = (f32 ? lds_bytes<float>(c, true) : lds_bytes<double>(c, true)) <= kLdsLimit;
     r.halo = r.fused_ola ? (c->W + c->H - 1) / c->H - 1 : 0;
     if (r.F > 0) {
         r.ana_tile = analysis_tile_len(c, group, r.F);
@@ -496,20 +514,21 @@ RtPlan roundtrip_plan(const voc_ctx *c, long long len, long long group, long lon
     }
     r.per_channel_bytes = (size_t)(2 * r.F * r.ldk + (long long)(r.syn_tiles > 1 ? r.syn_tiles : 0) * c->K + 2LL * c->K +
                                    (r.fused_ola ? 0 : r.F * c->W)) *
-                          sizeof(double);
+                          (f32 ? sizeof(float) : sizeof(double));
     return r;
 }
 
-void roundtrip_dev(voc_ctx *c, const double *x, long long x_stride, long long len, long long C, long long chunk,
-                   double *y, long long y_stride, double *ana_phase, double *syn_phase, double *leftover,
+template <class R>
+void roundtrip_dev(voc_ctx *c, const R *x, long long x_stride, long long len, long long C, long long chunk,
+                   R *y, long long y_stride, R *ana_phase, R *syn_phase, R *leftover,
                    long long leftover_stride, void *ws, long long ws_bytes, hipStream_t st)
 {
     if (C <= 0) return;
     const long long F = num_frames(c, len);
     const long long keep = leftover_length(c, len);
     if (leftover && keep > 0)
-        HIPCHK(hipMemcpy2DAsync(leftover, (size_t)leftover_stride * sizeof(double), x + (len - keep),
-                                (size_t)x_stride * sizeof(double), (size_t)keep * sizeof(double), (size_t)C,
+        HIPCHK(hipMemcpy2DAsync(leftover, (size_t)leftover_stride * sizeof(R), x + (len - keep),
+                                (size_t)x_stride * sizeof(R), (size_t)keep * sizeof(R), (size_t)C,
                                 hipMemcpyDeviceToDevice, st));
     if (F <= 0) return;
 
@@ -535,17 +554,17 @@ void roundtrip_dev(voc_ctx *c, const double *x, long long x_stride, long long le
     for (long long c0 = 0; c0 < C; c0 += group) {
         const long long G = (C - c0 < group) ? C - c0 : group;
         const RtPlan r = roundtrip_plan(c, len, group, chunk);
-        double *mag = static_cast<double *>(ws);
-        double *inc = mag + (size_t)G * F * r.ldk;
-        double *pinA = inc + (size_t)G * F * r.ldk;
-        double *pinS = pinA + (size_t)G * c->K;
-        double *carry = pinS + (size_t)G * c->K;
-        double *frames = carry + (size_t)(r.syn_tiles > 1 ? r.syn_tiles : 0) * G * c->K;  // only when !fused_ola
-        double *aph = ana_phase + c0 * c->K, *sph = syn_phase + c0 * c->K;
-        HIPCHK(hipMemcpyAsync(pinA, aph, (size_t)G * c->K * sizeof(double), hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipMemcpyAsync(pinS, sph, (size_t)G * c->K * sizeof(double), hipMemcpyDeviceToDevice, st));
+        R *mag = static_cast<R *>(ws);
+        R *inc = mag + (size_t)G * F * r.ldk;
+        R *pinA = inc + (size_t)G * F * r.ldk;
+        R *pinS = pinA + (size_t)G * c->K;
+        R *carry = pinS + (size_t)G * c->K;
+        R *frames = carry + (size_t)(r.syn_tiles > 1 ? r.syn_tiles : 0) * G * c->K;  // only when !fused_ola
+        R *aph = ana_phase + c0 * c->K, *sph = syn_phase + c0 * c->K;
+        HIPCHK(hipMemcpyAsync(pinA, aph, (size_t)G * c->K * sizeof(R), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(pinS, sph, (size_t)G * c->K * sizeof(R), hipMemcpyDeviceToDevice, st));
 
-        voc::AnaArgs a{};
+        voc::AnaArgsT<R> a{};
         a.x = x + c0 * x_stride;
         a.chan_stride = x_stride;
         a.frame_stride = c->H;  // framing fused: frame j starts at sample j*H (Frames.hs:34-35)
@@ -557,17 +576,19 @@ void roundtrip_dev(voc_ctx *c, const double *x, long long x_stride, long long le
         a.F = F;
         a.tile_len = r.ana_tile;
         a.tiles = r.ana_tiles;
-        a.vol = c->vol;  // volumeFix folded into the magnitude store (Conduit.hs:34-35)
-        if (!launch_analysis_fast(c, a, G, st)) launch_analysis<false, false>(c, a, G, st);
+        a.vol = (R)c->vol;  // volumeFix folded into the magnitude store (Conduit.hs:34-35)
+        bool done = false;
+        if constexpr (std::is_same<R, double>::value) done = launch_analysis_fast(c, a, G, st);
+        if (!done) launch_analysis<false, false, R>(c, a, G, st);
 
         if (r.syn_tiles > 1) {
             const long long chains = G * c->K;
             LaunchTimer timer(c, KIND_CARRY, st);
-            hipLaunchKernelGGL(voc::phase_carry_kernel, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st,
-                               c->params, inc, r.ldk, F, pinS, carry, r.syn_tile, r.syn_tiles, r.halo, G);
+            hipLaunchKernelGGL(voc::phase_carry_kernel<R>, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st,
+                               params_of<R>(c), (const R *)inc, r.ldk, F, (const R *)pinS, carry, r.syn_tile, r.syn_tiles, r.halo, G);
             HIPCHK(hipGetLastError());
         }
-        voc::SynArgs s{};
+        voc::SynArgsT<R> s{};
         s.mag = mag;
         s.inc = inc;
         s.ldk = r.ldk;
@@ -582,13 +603,17 @@ void roundtrip_dev(voc_ctx *c, const double *x, long long x_stride, long long le
         s.tiles = r.syn_tiles;
         s.halo = r.halo;
         if (r.fused_ola) {
-            if (!launch_synthesis_fast(c, s, G, true, st)) launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_OLA>(c, s, G, st);
+            done = false;
+            if constexpr (std::is_same<R, double>::value) done = launch_synthesis_fast(c, s, G, true, st);
+            if (!done) launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_OLA, R>(c, s, G, st);
         } else {
             // frame too long for an LDS-resident overlap-add ring: frames go through HBM once
             s.out = frames;
-            if (!launch_synthesis_fast(c, s, G, false, st)) launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_FRAMES>(c, s, G, st);
+            done = false;
+            if constexpr (std::is_same<R, double>::value) done = launch_synthesis_fast(c, s, G, false, st);
+            if (!done) launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_FRAMES, R>(c, s, G, st);
             const long long total = G * r.out_len;
-            hipLaunchKernelGGL(voc::sum_frames_kernel, dim3(ew_grid(total)), dim3(256), 0, st, frames, F, c->W, c->H,
+            hipLaunchKernelGGL(voc::sum_frames_kernel<R>, dim3(ew_grid(total)), dim3(256), 0, st, (const R *)frames, F, c->W, c->H,
                                y + c0 * y_stride, (long long)y_stride, r.out_len, total);
             HIPCHK(hipGetLastError());
         }
@@ -597,7 +622,12 @@ void roundtrip_dev(voc_ctx *c, const double *x, long long x_stride, long long le
 
 struct Locked {  // serialises calls on a context and pins its device for the calling thread
     std::lock_guard<std::mutex> g;
-    explicit Locked(voc_ctx *c) : g(c->mu) { HIPCHK(hipSetDevice(c->device)); }
+    // every entry point works in one precision; a context of the other one is refused
+    explicit Locked(voc_ctx *c, int precision = VOC_PRECISION_F64) : g(c->mu)
+    {
+        if (c->precision != precision) throw StatusFail{VOC_ERR_UNSUPPORTED};
+        HIPCHK(hipSetDevice(c->device));
+    }
 };
 
 }  // namespace
@@ -627,7 +657,7 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
     *out = nullptr;
     if (!window || W < 1 || H < 1 || N < 1) return VOC_ERR_INVALID;
     if (W > N) return VOC_ERR_INVALID;  // addZeroPadding: input longer than target length (Vocoder.hs:132)
-    if (precision != VOC_PRECISION_F64) return VOC_ERR_UNSUPPORTED;
+    if (precision != VOC_PRECISION_F64 && precision != VOC_PRECISION_F32) return VOC_ERR_UNSUPPORTED;
     if (N < 8 || N > 16384 || (N & (N - 1)) != 0) return VOC_ERR_UNSUPPORTED;
     voc_ctx *c = new (std::nothrow) voc_ctx;
     if (!c) return VOC_ERR_NOMEM;
@@ -637,6 +667,7 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
         if (device < 0 || device >= ndev) return VOC_ERR_INVALID;
         HIPCHK(hipSetDevice(device));
         c->N = N; c->W = W; c->H = H; c->K = N / 2 + 1; c->M = N / 2; c->device = device;
+        c->precision = precision;
         c->log2m = 0;
         while ((1 << c->log2m) < c->M) ++c->log2m;
         c->window.assign(window, window + W);
@@ -687,6 +718,41 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
         p.window = c->d_window;
         p.twP = c->d_twP;
         p.twS = c->d_twS;
+        if (precision == VOC_PRECISION_F32) {
+            // the same tables rounded once to float (twiddles from the long double values, not from the doubles)
+            std::vector<float> wf(window, window + W);
+            std::vector<float2> tpf(twP.size()), tsf(twS.size());
+            for (int ns = 1; ns < c->M;) {
+                const int rad = (c->M / ns) >= 8 ? 8 : (c->M / ns);
+                if (ns > 1)
+                    for (int j = 1; j < rad; ++j)
+                        for (int k = 0; k < ns; ++k) {
+                            const long double ang = two_pi * (long double)((long long)j * k) / (long double)((long long)ns * rad);
+                            tpf[(size_t)(ns - 1) + (size_t)(j - 1) * ns + k] = make_float2((float)cosl(ang), (float)-sinl(ang));
+                        }
+                ns *= rad;
+            }
+            for (int k = 0; k <= c->M / 2; ++k) {
+                const long double ang = two_pi * (long double)k / (long double)N;
+                tsf[k] = make_float2((float)cosl(ang), (float)-sinl(ang));
+            }
+            tsf[c->M / 2] = make_float2(0.0f, -1.0f);
+            HIPCHK(hipMalloc((void **)&c->d_window_f, sizeof(float) * (size_t)W));
+            HIPCHK(hipMalloc((void **)&c->d_twP_f, sizeof(float2) * tpf.size()));
+            HIPCHK(hipMalloc((void **)&c->d_twS_f, sizeof(float2) * tsf.size()));
+            HIPCHK(hipMemcpy(c->d_window_f, wf.data(), sizeof(float) * (size_t)W, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(c->d_twP_f, tpf.data(), sizeof(float2) * tpf.size(), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(c->d_twS_f, tsf.data(), sizeof(float2) * tsf.size(), hipMemcpyHostToDevice));
+            voc::ParamsT<float> &q = c->params_f;
+            q.N = N; q.W = W; q.H = H; q.K = c->K; q.M = c->M;
+            q.hd = p.hd; q.off = p.off; q.hop_pow2 = p.hop_pow2;
+            q.hop_d = (float)H;
+            q.inv_hop = 1.0f / (float)H;
+            q.inv_n = 1.0f / (float)N;
+            q.window = c->d_window_f;
+            q.twP = c->d_twP_f;
+            q.twS = c->d_twS_f;
+        }
         return VOC_OK;
     });
     if (rc != VOC_OK) {
@@ -705,6 +771,9 @@ VOC_EXPORT int32_t voc_ctx_destroy(voc_ctx *c)
     if (c->d_window) (void)hipFree(c->d_window);
     if (c->d_twP) (void)hipFree(c->d_twP);
     if (c->d_twS) (void)hipFree(c->d_twS);
+    if (c->d_window_f) (void)hipFree(c->d_window_f);
+    if (c->d_twP_f) (void)hipFree(c->d_twP_f);
+    if (c->d_twS_f) (void)hipFree(c->d_twS_f);
     delete c;
     return VOC_OK;
 }
@@ -955,7 +1024,7 @@ VOC_EXPORT int32_t voc_sum_frames(voc_ctx *c, const double *frames, int64_t F, i
         HIPCHK(hipMemcpy(dfr.p, frames, nfr, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(dy.p, y, ny, hipMemcpyHostToDevice));  // keeps the caller's bytes between rows
         const long long total = C * out_len;
-        hipLaunchKernelGGL(voc::sum_frames_kernel, dim3(ew_grid(total)), dim3(256), 0, nullptr, dfr.d(), (long long)F,
+        hipLaunchKernelGGL(voc::sum_frames_kernel<double>, dim3(ew_grid(total)), dim3(256), 0, nullptr, dfr.d(), (long long)F,
                            c->W, c->H, dy.d(), (long long)y_stride, out_len, total);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpy(y, dy.p, ny, hipMemcpyDeviceToHost));
@@ -1070,6 +1139,64 @@ VOC_EXPORT int32_t voc_roundtrip(voc_ctx *c, const double *x, int64_t x_stride, 
     });
 }
 
+// ---- fused path, single precision ---------------------------------------------------------------------
+
+VOC_EXPORT int32_t voc_roundtrip_f32_dev(voc_ctx *c, const float *x, int64_t x_stride, int64_t len, int64_t C,
+                                         int64_t chunk, float *y, int64_t y_stride, float *ana_phase_io,
+                                         float *syn_phase_io, float *leftover, int64_t leftover_stride,
+                                         void *workspace, int64_t workspace_bytes, void *stream)
+{
+    if (!c || C < 0 || len < 0 || chunk < 1 || x_stride < len) return VOC_ERR_INVALID;
+    if (C == 0) return VOC_OK;
+    const long long F = num_frames(c, len);
+    if (!x || !ana_phase_io || !syn_phase_io) return VOC_ERR_INVALID;
+    if (F > 0 && (!y || y_stride < ola_length(c, F, chunk))) return VOC_ERR_SIZE;
+    if (leftover && leftover_stride < leftover_length(c, len)) return VOC_ERR_SIZE;
+    if (workspace && workspace_bytes < 0) return VOC_ERR_INVALID;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c, VOC_PRECISION_F32);
+        roundtrip_dev<float>(c, x, x_stride, len, C, chunk, y, y_stride, ana_phase_io, syn_phase_io, leftover,
+                             leftover_stride, workspace, workspace_bytes, (hipStream_t)stream);
+        return VOC_OK;
+    });
+}
+
+VOC_EXPORT int32_t voc_roundtrip_f32(voc_ctx *c, const float *x, int64_t x_stride, int64_t len, int64_t C, int64_t chunk,
+                                     float *y, int64_t y_stride, float *ana_phase_io, float *syn_phase_io,
+                                     float *leftover, int64_t leftover_stride)
+{
+    if (!c || C < 0 || len < 0 || chunk < 1 || x_stride < len) return VOC_ERR_INVALID;
+    if (C == 0) return VOC_OK;
+    const long long F = num_frames(c, len), out_len = ola_length(c, F, chunk), keep = leftover_length(c, len);
+    if (!x || !ana_phase_io || !syn_phase_io) return VOC_ERR_INVALID;
+    if (F > 0 && (!y || y_stride < out_len)) return VOC_ERR_SIZE;
+    if (leftover && leftover_stride < keep) return VOC_ERR_SIZE;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c, VOC_PRECISION_F32);
+        const size_t e = sizeof(float);
+        const size_t nx = (size_t)C * len * e, ny = (size_t)C * out_len * e, nph = (size_t)C * c->K * e,
+                     nl = (size_t)C * keep * e;
+        DevBuf dx(nx), dy(ny), da(nph), ds(nph), dl(nl);
+        HIPCHK(hipMemcpy2DAsync(dx.p, (size_t)len * e, x, (size_t)x_stride * e, (size_t)len * e, (size_t)C,
+                                hipMemcpyHostToDevice, nullptr));
+        HIPCHK(hipMemcpy(da.p, ana_phase_io, nph, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ds.p, syn_phase_io, nph, hipMemcpyHostToDevice));
+        roundtrip_dev<float>(c, static_cast<float *>(dx.p), len, len, C, chunk, static_cast<float *>(dy.p), out_len,
+                             static_cast<float *>(da.p), static_cast<float *>(ds.p),
+                             leftover ? static_cast<float *>(dl.p) : nullptr, keep, nullptr, 0, nullptr);
+        HIPCHK(hipStreamSynchronize(nullptr));
+        if (out_len > 0)
+            HIPCHK(hipMemcpy2DAsync(y, (size_t)y_stride * e, dy.p, (size_t)out_len * e, (size_t)out_len * e, (size_t)C,
+                                    hipMemcpyDeviceToHost, nullptr));
+        if (leftover && keep > 0)
+            HIPCHK(hipMemcpy2DAsync(leftover, (size_t)leftover_stride * e, dl.p, (size_t)keep * e, (size_t)keep * e,
+                                    (size_t)C, hipMemcpyDeviceToHost, nullptr));
+        HIPCHK(hipMemcpy(ana_phase_io, da.p, nph, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(syn_phase_io, ds.p, nph, hipMemcpyDeviceToHost));
+        return VOC_OK;
+    });
+}
+
 // ---- measurement hook -----------------------------------------------------------------------------------------
 
 VOC_EXPORT int32_t voc_profile_enable(voc_ctx *c, int32_t on)
@@ -1090,7 +1217,7 @@ VOC_EXPORT int32_t voc_profile_read(voc_ctx *c, double *ms, int64_t *launches)
     for (int k = 0; k < KIND_COUNT; ++k) { ms[k] = 0.0; launches[k] = 0; }
 #ifndef VOC_EMU
     return guarded(c, [&]() -> int32_t {
-        Locked lk(c);
+        Locked lk(c, c->precision);
         for (auto &t : c->timed) {
             float e = 0.f;
             HIPCHK(hipEventSynchronize(t.stop));

@@ -35,12 +35,18 @@ class VocoderParams:
     """`VocoderParams` (Vocoder.hs:89-99): the two FFT plans, hop size and window, held by the
     library as one opaque context."""
 
-    def __init__(self, frame_length: int, hop_size: int, window, device: int = 0, lib: Library | None = None):
+    def __init__(self, frame_length: int, hop_size: int, window, device: int = 0, lib: Library | None = None,
+                 precision: str = "f64"):
+        """precision "f32" makes a context of the single-precision variant: only the fused round trip
+        (`conduit.process_with`, `conduit.process_dev`) is available on it."""
         self.lib = lib or default_library()
+        self.precision = precision
+        if precision not in ("f64", "f32"):
+            raise ValueError("precision must be 'f64' or 'f32'")
         window = _f64(window).ravel()
         h = C.c_void_p()
         st = self.lib.dll.voc_ctx_create(int(frame_length), int(hop_size), _p(window), int(window.size), int(device),
-                                         0, C.byref(h))
+                                         1 if precision == "f32" else 0, C.byref(h))
         if st == -1 and window.size > frame_length:
             # addZeroPadding's `error` (Vocoder.hs:132)
             raise VocoderError(st, f"addZeroPadding: input is {window.size - frame_length} samples longer than target length")
