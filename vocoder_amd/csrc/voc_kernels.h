@@ -399,24 +399,81 @@ VOC_DEV double hs_wrap(double e)
     return (n - t) - kPi;
 }
 
-// ---- single precision: the same definitions on float.  magnitude keeps the scaled form, the
-// phase is the device library's atan2f with the reference's 0 for 0:+0, sin / cos are the device
-// library's (accurate for every float), wrap keeps the floored-modulus shape.
+// ---- single precision: the same definitions on float.
+VOC_DEV float approx_rcp(float b)
+{
+#ifdef VOC_EMU
+    return 1.0f / b;
+#else
+    return __builtin_amdgcn_rcpf(b);
+#endif
+}
+
+VOC_DEV int frexp_exponent(float v)
+{
+#ifdef VOC_EMU
+    int e = 0;
+    if (v != 0.0f) (void)frexpf(v, &e);
+    return e;
+#else
+    return __builtin_amdgcn_frexp_expf(v);
+#endif
+}
+
+// Same construction as the double version: shared power-of-two scaling, one division placed
+// after the fold at tan(pi/8), atan(t) = t + t z P(z) with a degree-4 minimax P (error 2.5e-9).
 VOC_DEV void hs_polar(float x, float y, float &mag, float &ph)
 {
     const float ax = fabsf(x), ay = fabsf(y);
-    int e = 0;
-    const float mx = fmaxf(ax, ay);
-    if (mx != 0.0f) (void)frexpf(mx, &e);
+    const int e = frexp_exponent(fmaxf(ax, ay));
     const float sx = ldexpf(ax, -e), sy = ldexpf(ay, -e);
+    const bool is_zero = ax == 0.0f && ay == 0.0f;
+#ifdef VOC_EMU
     mag = ldexpf(sqrtf(sx * sx + sy * sy), e);
-    ph = (ax == 0.0f && ay == 0.0f) ? 0.0f : atan2f(y, x);
+#else
+    mag = ldexpf(__builtin_amdgcn_sqrtf(sx * sx + sy * sy), e);
+#endif
+    const float mx = fmaxf(sx, sy), mn = fminf(sx, sy);
+    const bool fold = mn > 0.41421356f * mx;
+    const float num = fold ? mn - mx : mn;
+    const float den = fold ? mn + mx : mx;
+    const float r = approx_rcp(den);
+    float q = num * r;
+    q = fmaf(fmaf(-den, q, num), r, q);
+    const float z = q * q;
+    float p = -0.06466829776763916f;
+    p = fmaf(p, z, 0.10748856514692307f);
+    p = fmaf(p, z, -0.14264507591724396f);
+    p = fmaf(p, z, 0.19999559223651886f);
+    p = fmaf(p, z, -0.3333333134651184f);
+    float t = fmaf(q * z, p, q);
+    t = fold ? t + 0.78539816f : t;
+    t = (ay > ax) ? 1.57079633f - t : t;
+    t = __builtin_signbit(x) ? 3.14159265f - t : t;
+    ph = is_zero ? 0.0f : copysignf(t, y);
 }
 
+// sin and cos of a phase of moderate size (the float variant keeps its phases wrapped): Cody-Waite
+// reduction by pi/2 in two fma steps, minimax kernels on [-pi/4, pi/4] (errors 1.2e-8 / 8e-10).
 VOC_DEV void fast_sincos(float x, float *sn, float *cs)
 {
-    *sn = sinf(x);
-    *cs = cosf(x);
+    const float n = rintf(x * 0.636619772f);
+    const int q = (int)n;
+    float r = fmaf(-n, 1.57079637f, x);
+    r = fmaf(-n, -4.37113883e-8f, r);
+    const float z = r * r;
+    float ps = -0.00019588008581195027f;
+    ps = fmaf(ps, z, 0.008332748897373676f);
+    ps = fmaf(ps, z, -0.166666641831398f);
+    const float s = fmaf(r * z, ps, r);
+    float pc = 2.454804052831605e-05f;
+    pc = fmaf(pc, z, -0.001388830365613103f);
+    pc = fmaf(pc, z, 0.0416666641831398f);
+    const float c = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+    const float s1 = (q & 1) ? c : s;
+    const float c1 = (q & 1) ? s : c;
+    *sn = (q & 2) ? -s1 : s1;
+    *cs = ((q + 1) & 2) ? -c1 : c1;
 }
 
 VOC_DEV float hs_wrap(float e)

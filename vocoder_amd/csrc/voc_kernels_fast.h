@@ -49,18 +49,20 @@ struct FastCfg {
     static constexpr int R4 = M / 512;               // radix of the fourth pass (1: there is none)
     static constexpr int NB4 = R4 > 1 ? 8 / R4 : 1;  // fourth-pass butterflies per thread
     static constexpr int LDS_CPLX = Cfg<LOG2M>::LDS_CPLX;
-    static constexpr int LDS_BYTES = LDS_CPLX * 16 + ((K + 1) & ~1) * 8;
+    static constexpr int LDS_BYTES = LDS_CPLX * 16 + ((K + 1) & ~1) * 8;  // double
+    template <class R> static constexpr int lds_bytes() { return (LDS_CPLX * 2 + ((K + 1) & ~1)) * (int)sizeof(R); }
 };
 
 // real-FFT split of the pair (Z[pe], Z[q]), q = M - pe:  X[pe] = E + W^pe O,  X[q] = conj(E - W^pe O)
 // with E = (P + conj Q)/2, O = (P - conj Q)/(2i).  Returned are 2 X[pe] and 2 X[q]: the halvings are
 // left out (exact powers of two: the phase is unchanged, the magnitude is exactly doubled and the
 // caller folds the 1/2 into its volume factor).
-VOC_DEV void split_pair_x2(double2 P, double2 Q, double2 tw, double2 &Xa, double2 &Xb)
+template <class C2>
+VOC_DEV void split_pair_x2(C2 P, C2 Q, C2 tw, C2 &Xa, C2 &Xb)
 {
-    const double2 E = make_double2(P.x + Q.x, P.y - Q.y);
-    const double2 O = make_double2(P.y + Q.y, Q.x - P.x);
-    const double2 U = cmul(tw, O);
+    const C2 E = mk2(P.x + Q.x, P.y - Q.y);
+    const C2 O = mk2(P.y + Q.y, Q.x - P.x);
+    const C2 U = cmul(tw, O);
     Xa = cadd(E, U);
     Xb = cconj(csub(E, U));
 }
@@ -68,13 +70,14 @@ VOC_DEV void split_pair_x2(double2 P, double2 Q, double2 tw, double2 &Xa, double
 // inverse of split_pair, without the factor 1/2 (folded into the final 1/N):
 // Z[pe] = S + i Tw, Z[q] = conj S + i conj Tw with S = A + conj B, Tw = W^-pe (A - conj B);
 // both are returned with re and im swapped (the forward FFT then performs the backward transform).
-VOC_DEV void merge_pair(double2 A, double2 B, double2 tw, double2 &Za, double2 &Zb)
+template <class C2>
+VOC_DEV void merge_pair(C2 A, C2 B, C2 tw, C2 &Za, C2 &Zb)
 {
-    const double2 S = make_double2(A.x + B.x, A.y - B.y);
-    const double2 D = make_double2(A.x - B.x, A.y + B.y);
-    const double2 Tw = cmul_conj(D, tw);
-    Za = make_double2(S.y + Tw.x, S.x - Tw.y);
-    Zb = make_double2(Tw.x - S.y, S.x + Tw.y);
+    const C2 S = mk2(A.x + B.x, A.y - B.y);
+    const C2 D = mk2(A.x - B.x, A.y + B.y);
+    const C2 Tw = cmul_conj(D, tw);
+    Za = mk2(S.y + Tw.x, S.x - Tw.y);
+    Zb = mk2(Tw.x - S.y, S.x + Tw.y);
 }
 
 // ---- the four Stockham passes, split into load / compute / store so that callers can place
@@ -88,7 +91,8 @@ VOC_DEV void merge_pair(double2 A, double2 B, double2 tw, double2 &Za, double2 &
 // Marks a register-resident value as changed without emitting an instruction.  Everything derived
 // from the frame-invariant twiddle bases below is loop invariant, and the compiler would otherwise
 // hoist all of it (84 registers of twiddle powers) out of the frame loop and spill it.
-VOC_DEV void opaque(double2 &a)
+template <class C2>
+VOC_DEV void opaque(C2 &a)
 {
 #ifndef VOC_EMU
     asm volatile("" : "+v"(a.x), "+v"(a.y));
@@ -115,66 +119,70 @@ VOC_DEV void sched_fence()
 #endif
 }
 
-VOC_DEV double2 csqr(double2 a) { return make_double2(fma(a.x, a.x, -(a.y * a.y)), (a.x + a.x) * a.y); }
+template <class C2>
+VOC_DEV C2 csqr(C2 a) { return mk2(fma(a.x, a.x, -(a.y * a.y)), (a.x + a.x) * a.y); }
 
-template <int LOG2M>
+template <int LOG2M, class C2>
 struct FastTw {
-    double2 b, c;                           // base factors of the passes at stride 8 and 64
-    double2 d[FastCfg<LOG2M>::NB4];         // base factors of the fourth pass (stride 512), one per butterfly
-    double2 s;                              // exp(-2 pi i tid / N): base of the split twiddles
+    C2 b, c;                           // base factors of the passes at stride 8 and 64
+    C2 d[FastCfg<LOG2M>::NB4];         // base factors of the fourth pass (stride 512), one per butterfly
+    C2 s;                              // exp(-2 pi i tid / N): base of the split twiddles
 };
 
-template <int LOG2M>
-VOC_DEV void fast_tw_init(const Params &p, int tid, FastTw<LOG2M> &t)
+template <int LOG2M, class R>
+VOC_DEV void fast_tw_init(const ParamsT<R> &p, int tid, FastTw<LOG2M, cplx<R>> &t)
 {
     constexpr int T = FastCfg<LOG2M>::T, R4 = FastCfg<LOG2M>::R4;
     t.b = p.twP[7 + (tid & 7)];
     t.c = p.twP[63 + (tid & 63)];
 #pragma unroll
-    for (int q = 0; q < FastCfg<LOG2M>::NB4; ++q) t.d[q] = R4 > 1 ? p.twP[511 + ((tid + q * T) & 511)] : make_double2(1.0, 0.0);
+    for (int q = 0; q < FastCfg<LOG2M>::NB4; ++q) t.d[q] = R4 > 1 ? p.twP[511 + ((tid + q * T) & 511)] : mk2((R)1, (R)0);
     t.s = p.twS[tid];
 }
 
 // split twiddle of bin pair slot m of this thread: exp(-2 pi i (tid + m T) / N) = s * exp(-2 pi i m / 16);
 // thread 0's slot 0 holds the self-paired bin M/2 instead, whose factor is exp(-i pi/2) = -i exactly.
-VOC_DEV double2 split_tw(double2 s, int m, bool self_pair)
+template <class C2>
+VOC_DEV C2 split_tw(C2 s, int m, bool self_pair)
 {
+    using R = decltype(s.x);
     opaque(s);
-    const double cr = m == 0 ? 1.0 : (m == 1 ? 0.92387953251128673848 : (m == 2 ? 0.70710678118654752440 : 0.38268343236508977173));
-    const double ci = m == 0 ? 0.0 : (m == 1 ? -0.38268343236508977173 : (m == 2 ? -0.70710678118654752440 : -0.92387953251128673848));
-    const double2 w = cmul(s, make_double2(cr, ci));  // m == 0: s * (1, 0) = s exactly
-    return self_pair ? make_double2(0.0, -1.0) : w;
+    const R cr = (R)(m == 0 ? 1.0 : (m == 1 ? 0.92387953251128673848 : (m == 2 ? 0.70710678118654752440 : 0.38268343236508977173)));
+    const R ci = (R)(m == 0 ? 0.0 : (m == 1 ? -0.38268343236508977173 : (m == 2 ? -0.70710678118654752440 : -0.92387953251128673848)));
+    const C2 w = cmul(s, mk2(cr, ci));  // m == 0: s * (1, 0) = s exactly
+    return self_pair ? mk2((R)0, (R)-1) : w;
 }
 
-template <int LOG2M>
-VOC_DEV void load8(const double2 *lds, int tid, double2 (&v)[8])
+template <int LOG2M, class C2>
+VOC_DEV void load8(const C2 *lds, int tid, C2 (&v)[8])
 {
     constexpr int T = FastCfg<LOG2M>::T;
-    const double2 *src = lds + lds_pad(tid);
+    const C2 *src = lds + lds_pad(tid);
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = src[j * (T + T / 8)];
 }
 
-template <int LOG2M, int NS>  // store of a radix-8 pass at stride NS (1, 8 or 64)
-VOC_DEV void store8(double2 *lds, int tid, const double2 (&v)[8])
+template <int LOG2M, int NS, class C2>  // store of a radix-8 pass at stride NS (1, 8 or 64)
+VOC_DEV void store8(C2 *lds, int tid, const C2 (&v)[8])
 {
     const int k = tid & (NS - 1);
-    double2 *dst = lds + lds_pad((tid - k) * 8 + k);
+    C2 *dst = lds + lds_pad((tid - k) * 8 + k);
     constexpr int STEP = NS == 1 ? 1 : NS + NS / 8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) dst[j * STEP] = v[j];
 }
 
 // v[j] *= w^j, j = 1..7
-VOC_DEV void twiddle8(double2 (&v)[8], double2 w1)
+template <class C2>
+VOC_DEV void twiddle8(C2 (&v)[8], C2 w1)
 {
     opaque(w1);
-    const double2 w2 = csqr(w1);
+    const C2 w2 = csqr(w1);
     v[1] = cmul(v[1], w1);
     v[2] = cmul(v[2], w2);
-    const double2 w3 = cmul(w2, w1);
+    const C2 w3 = cmul(w2, w1);
     v[3] = cmul(v[3], w3);
-    const double2 w4 = csqr(w2);
+    const C2 w4 = csqr(w2);
     v[4] = cmul(v[4], w4);
     v[5] = cmul(v[5], cmul(w4, w1));
     v[6] = cmul(v[6], csqr(w3));
@@ -182,28 +190,28 @@ VOC_DEV void twiddle8(double2 (&v)[8], double2 w1)
 }
 
 // fourth pass: load, twiddle, butterfly (results stay in v); pass4_store writes them
-template <int LOG2M>
-VOC_DEV void pass4_compute(const double2 *lds, int tid, const FastTw<LOG2M> &t, double2 (&v)[8])
+template <int LOG2M, class C2>
+VOC_DEV void pass4_compute(const C2 *lds, int tid, const FastTw<LOG2M, C2> &t, C2 (&v)[8])
 {
     constexpr int R4 = FastCfg<LOG2M>::R4, T = FastCfg<LOG2M>::T, M = FastCfg<LOG2M>::M;
     if constexpr (R4 > 1) {
         constexpr int NBF = M / R4;
 #pragma unroll
         for (int q = 0; q < FastCfg<LOG2M>::NB4; ++q) {
-            const double2 *src = lds + lds_pad(tid + q * T);
-            double2 w[R4];
+            const C2 *src = lds + lds_pad(tid + q * T);
+            C2 w[R4];
 #pragma unroll
             for (int j = 0; j < R4; ++j) w[j] = src[j * (NBF + NBF / 8)];
-            double2 pw = t.d[q];
+            C2 pw = t.d[q];
             opaque(pw);
             w[1] = cmul(w[1], pw);
             if constexpr (R4 >= 4) {
-                const double2 w2 = csqr(pw);
+                const C2 w2 = csqr(pw);
                 w[2] = cmul(w[2], w2);
-                const double2 w3 = cmul(w2, pw);
+                const C2 w3 = cmul(w2, pw);
                 w[3] = cmul(w[3], w3);
                 if constexpr (R4 == 8) {
-                    const double2 w4 = csqr(w2);
+                    const C2 w4 = csqr(w2);
                     w[4] = cmul(w[4], w4);
                     w[5] = cmul(w[5], cmul(w4, pw));
                     w[6] = cmul(w[6], csqr(w3));
@@ -217,8 +225,8 @@ VOC_DEV void pass4_compute(const double2 *lds, int tid, const FastTw<LOG2M> &t, 
     }
 }
 
-template <int LOG2M>
-VOC_DEV void pass4_store(double2 *lds, int tid, const double2 (&v)[8])
+template <int LOG2M, class C2>
+VOC_DEV void pass4_store(C2 *lds, int tid, const C2 (&v)[8])
 {
     constexpr int R4 = FastCfg<LOG2M>::R4, T = FastCfg<LOG2M>::T;
     if constexpr (R4 > 1) {
@@ -226,7 +234,7 @@ VOC_DEV void pass4_store(double2 *lds, int tid, const double2 (&v)[8])
         for (int q = 0; q < FastCfg<LOG2M>::NB4; ++q) {
             const int i = tid + q * T;
             const int k = i & 511;
-            double2 *dst = lds + lds_pad((i - k) * R4 + k);
+            C2 *dst = lds + lds_pad((i - k) * R4 + k);
 #pragma unroll
             for (int j = 0; j < R4; ++j) dst[j * 576] = v[q * R4 + j];
         }
@@ -236,8 +244,8 @@ VOC_DEV void pass4_store(double2 *lds, int tid, const double2 (&v)[8])
 // Passes 2..4 of the transform whose first-pass butterflies are already in v.  `prefetch` is
 // called once, after the last butterfly and before the last store: the place for the caller's
 // next-frame loads.
-template <int LOG2M, class Prefetch>
-VOC_DEV void fft_after_first(double2 *lds, const FastTw<LOG2M> &t, int tid, double2 (&v)[8], Prefetch prefetch)
+template <int LOG2M, class C2, class Prefetch>
+VOC_DEV void fft_after_first(C2 *lds, const FastTw<LOG2M, C2> &t, int tid, C2 (&v)[8], Prefetch prefetch)
 {
     constexpr int R4 = FastCfg<LOG2M>::R4;
     __syncthreads();
@@ -272,57 +280,58 @@ VOC_DEV void fft_after_first(double2 *lds, const FastTw<LOG2M> &t, int tid, doub
 // the frame; the next frame is the same window moved by H, i.e. by SLIDE pair slots, so only the
 // SLIDE newest pairs are loaded.  Every input sample is then fetched once per workgroup instead of
 // N/H times (those re-reads were missing L2: measured 3.2x the unique input bytes).
-template <int LOG2M, bool VEC2, int SLIDE>
-__global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fast_kernel(Params p, AnaArgs a)
+template <int LOG2M, bool VEC2, int SLIDE, class R = double>
+__global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fast_kernel(ParamsT<R> p, AnaArgsT<R> a)
 {
+    using C2 = cplx<R>;
     constexpr int M = FastCfg<LOG2M>::M, T = FastCfg<LOG2M>::T;
     constexpr int NEW = SLIDE > 0 ? SLIDE : 8;  // pair slots loaded per frame
-    VOC_SMEM(double2, lds);
-    double *php = reinterpret_cast<double *>(lds + FastCfg<LOG2M>::LDS_CPLX);  // previous raw phase, K bins
+    VOC_SMEM(C2, lds);
+    R *php = reinterpret_cast<R *>(lds + FastCfg<LOG2M>::LDS_CPLX);  // previous raw phase, K bins
     const int tid = threadIdx.x;
     const long long c = blockIdx.x / a.tiles;
     const int tile = blockIdx.x % a.tiles;
     const long long f0 = (long long)tile * a.tile_len;
     const long long f1 = (f0 + a.tile_len < a.F) ? f0 + a.tile_len : a.F;
-    const double *xc = a.x + c * a.chan_stride;
+    const R *xc = a.x + c * a.chan_stride;
 
     if (f0 == 0) {
-        const double *pi = a.phase_in + c * p.K;
+        const R *pi = a.phase_in + c * p.K;
         for (int k = tid; k < p.K; k += T) php[k] = pi[k];
     }
     // (ownership of php differs between this fill and the loop below; the barriers inside the
     //  FFT separate them)
 
-    FastTw<LOG2M> tw;  // frame-invariant twiddle bases of this thread
+    FastTw<LOG2M, C2> tw;  // frame-invariant twiddle bases of this thread
     fast_tw_init<LOG2M>(p, tid, tw);
 
     // Slot u holds the sample pair at frame positions 2 tid + 2 u T (+1).  The first FFT pass reads
     // the frame rewound (v[n] = padded[(n + N/2) mod N]) and even/odd packed: its element
     // tid + j T is slot (j + 4) mod 8.
-    double2 xs[8], xn[NEW], ws[8];
-    auto sample_pair = [&](const double *fr, int u) -> double2 {
+    C2 xs[8], xn[NEW], ws[8];
+    auto sample_pair = [&](const R *fr, int u) -> C2 {
         const unsigned i0 = (unsigned)(2 * (tid + u * T));  // unsigned: SGPR base + 32-bit lane offset
-        if (VEC2) return *reinterpret_cast<const double2 *>(fr + i0);
+        if (VEC2) return *reinterpret_cast<const C2 *>(fr + i0);
         const int j0 = (int)i0 - p.hd, j1 = j0 + 1;
-        return make_double2((j0 >= 0 && j0 < p.W) ? fr[j0] : 0.0, (j1 >= 0 && j1 < p.W) ? fr[j1] : 0.0);
+        return mk2((j0 >= 0 && j0 < p.W) ? fr[j0] : (R)0, (j1 >= 0 && j1 < p.W) ? fr[j1] : (R)0);
     };
     auto load_window = [&]() {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const unsigned i0 = (unsigned)(2 * (tid + u * T));
             if (VEC2) {
-                ws[u] = *reinterpret_cast<const double2 *>(p.window + i0);
+                ws[u] = *reinterpret_cast<const C2 *>(p.window + i0);
             } else {
                 const int j0 = (int)i0 - p.hd, j1 = j0 + 1;
-                ws[u] = make_double2((j0 >= 0 && j0 < p.W) ? p.window[j0] : 0.0, (j1 >= 0 && j1 < p.W) ? p.window[j1] : 0.0);
+                ws[u] = mk2((j0 >= 0 && j0 < p.W) ? p.window[j0] : (R)0, (j1 >= 0 && j1 < p.W) ? p.window[j1] : (R)0);
             }
         }
     };
 
-    const double half_vol = 0.5 * a.vol;  // exact; undoes the doubling of split_pair_x2
+    const R half_vol = (R)0.5 * a.vol;  // exact; undoes the doubling of split_pair_x2
     const long long fs = f0 > 0 ? f0 - 1 : f0;  // one frame early to recover its raw phase
     {
-        const double *fr = xc + fs * a.frame_stride;
+        const R *fr = xc + fs * a.frame_stride;
 #pragma unroll
         for (int u = 0; u < 8; ++u) xs[u] = sample_pair(fr, u);
         load_window();
@@ -330,16 +339,16 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
     for (long long f = fs; f < f1; ++f) {
         const bool emit = f >= f0;
         if (!(VEC2 && VOC_WS_PREFETCH) && f > fs) load_window();  // predicated loads: not worth the registers of a prefetch
-        double2 v[8];
+        C2 v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int u = (j + 4) & 7;
-            v[j] = make_double2(ws[u].x * xs[u].x, ws[u].y * xs[u].y);
+            v[j] = mk2(ws[u].x * xs[u].x, ws[u].y * xs[u].y);
         }
         dft<8>(v);
         fft_after_first<LOG2M>(lds, tw, tid, v, [&]() {
             if (f + 1 < f1) {  // the pairs of the next frame that are not already in registers, and the window again
-                const double *fr = xc + (f + 1) * a.frame_stride;
+                const R *fr = xc + (f + 1) * a.frame_stride;
 #pragma unroll
                 for (int i = 0; i < NEW; ++i) xn[i] = sample_pair(fr, 8 - NEW + i);
                 if (VEC2 && VOC_WS_PREFETCH) load_window();
@@ -347,16 +356,16 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
         });
 
         const long long row = c * a.F + f;
-        double *mrow = a.mag + row * a.ldk, *irow = a.inc + row * a.ldk;
+        R *mrow = a.mag + row * a.ldk, *irow = a.inc + row * a.ldk;
 VOC_UNROLL(VOC_POLAR_UNROLL)
         for (int m = 0; m < 4; ++m) {
             const unsigned pr = tid + m * T;
             const unsigned pe = pr == 0 ? M / 2 : pr;
             const unsigned q = M - pe;
-            double2 Xa, Xb;
+            C2 Xa, Xb;
             split_pair_x2(lds[lds_pad(pe)], lds[lds_pad(q)], split_tw(tw.s, m, pr == 0), Xa, Xb);
-            const double pa = php[pe], pb = php[q];
-            double ma, mb, pha, phb;
+            const R pa = php[pe], pb = php[q];
+            R ma, mb, pha, phb;
             hs_polar(Xa.x, Xa.y, ma, pha);
             hs_polar(Xb.x, Xb.y, mb, phb);
             if (emit) {
@@ -369,9 +378,9 @@ VOC_UNROLL(VOC_POLAR_UNROLL)
             php[q] = phb;
         }
         if (tid == 0) {  // DC and Nyquist bins are real: phase 0 or pi, magnitude |x|
-            const double2 z0 = lds[lds_pad(0)];
-            const double x0 = z0.x + z0.y, xm = z0.x - z0.y;
-            const double ph0 = x0 < 0.0 ? kPi : 0.0, phm = xm < 0.0 ? kPi : 0.0;
+            const C2 z0 = lds[lds_pad(0)];
+            const R x0 = z0.x + z0.y, xm = z0.x - z0.y;
+            const R ph0 = x0 < (R)0 ? (R)kPi : (R)0, phm = xm < (R)0 ? (R)kPi : (R)0;
             if (emit) {
                 mrow[0] = fabs(x0) * a.vol;
                 mrow[M] = fabs(xm) * a.vol;
@@ -391,7 +400,7 @@ VOC_UNROLL(VOC_POLAR_UNROLL)
 
     if (f1 == a.F && f1 > f0) {
         __syncthreads();
-        double *po = a.phase_out + c * p.K;
+        R *po = a.phase_out + c * p.K;
         for (int k = tid; k < p.K; k += T) po[k] = php[k];
     }
 }
@@ -401,16 +410,17 @@ VOC_UNROLL(VOC_POLAR_UNROLL)
 // PAIRS (2(t + jT), 2(t + jT) + 1), j = 0..7, of the N-sample window -- one complex LDS element,
 // one 16-byte window load and one 16-byte store per pair -- and the partial sums shift by NHP
 // pairs per frame.  y rows must be 16-byte aligned.
-template <int LOG2M, bool OLA, int NHP>
-__global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_fast_kernel(Params p, SynArgs a)
+template <int LOG2M, bool OLA, int NHP, class R = double>
+__global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_fast_kernel(ParamsT<R> p, SynArgsT<R> a)
 {
+    using C2 = cplx<R>;
     constexpr int M = FastCfg<LOG2M>::M, T = FastCfg<LOG2M>::T, N = 2 * M;
     constexpr int NP = 8;                       // sample pairs per thread
     constexpr int NK = OLA ? NP - NHP : 0;      // pairs whose partial sums outlive the frame
     constexpr int NT = NK > 0 ? NK : 1;         // (array length: never zero)
-    VOC_SMEM(double2, lds);
-    double *php = reinterpret_cast<double *>(lds + FastCfg<LOG2M>::LDS_CPLX);  // accumulated phase, K bins
-    const double *ldsd = reinterpret_cast<const double *>(lds);
+    VOC_SMEM(C2, lds);
+    R *php = reinterpret_cast<R *>(lds + FastCfg<LOG2M>::LDS_CPLX);  // accumulated phase, K bins
+    const R *ldsd = reinterpret_cast<const R *>(lds);
     const int tid = threadIdx.x;
     const long long c = blockIdx.x / a.tiles;
     const int tile = blockIdx.x % a.tiles;
@@ -420,21 +430,21 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
     const long long fs = f0 - halo;
 
     {
-        const double *pi = (tile == 0) ? a.phase_in + c * p.K : a.carry + (c * a.tiles + tile) * p.K;
+        const R *pi = (tile == 0) ? a.phase_in + c * p.K : a.carry + (c * a.tiles + tile) * p.K;
         for (int k = tid; k < p.K; k += T) php[k] = pi[k];
     }
     __syncthreads();
 
-    FastTw<LOG2M> tw;  // frame-invariant twiddle bases of this thread
+    FastTw<LOG2M, C2> tw;  // frame-invariant twiddle bases of this thread
     fast_tw_init<LOG2M>(p, tid, tw);
-    double2 tail[NT];  // overlap-add partial sums that later frames still add to
+    C2 tail[NT];  // overlap-add partial sums that later frames still add to
 #pragma unroll
-    for (int j = 0; j < NT; ++j) tail[j] = make_double2(0.0, 0.0);
+    for (int j = 0; j < NT; ++j) tail[j] = mk2((R)0, (R)0);
 
     // STFT row of frame f: (mag, ph_inc) of this thread's eight bins, plus DC / Nyquist for thread 0
-    double mg[8], ic[8], mg0 = 0.0, mgm = 0.0, ic0 = 0.0, icm = 0.0;
+    R mg[8], ic[8], mg0 = (R)0, mgm = (R)0, ic0 = (R)0, icm = (R)0;
     auto load_row = [&](long long f, int lt) {
-        const double *mrow = a.mag + (c * a.F + f) * a.ldk, *irow = a.inc + (c * a.F + f) * a.ldk;
+        const R *mrow = a.mag + (c * a.F + f) * a.ldk, *irow = a.inc + (c * a.F + f) * a.ldk;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const unsigned pr = lt + m * T;
@@ -462,12 +472,12 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
             const unsigned pr = lt + m * T;
             const unsigned pe = pr == 0 ? M / 2 : pr;
             const unsigned q = M - pe;
-            double pa = php[pe], pb = php[q];
-            const double2 A = synthesize_bin(p, mg[2 * m], ic[2 * m], pa);
-            const double2 B = synthesize_bin(p, mg[2 * m + 1], ic[2 * m + 1], pb);
+            R pa = php[pe], pb = php[q];
+            const C2 A = synthesize_bin(p, mg[2 * m], ic[2 * m], pa);
+            const C2 B = synthesize_bin(p, mg[2 * m + 1], ic[2 * m + 1], pb);
             php[pe] = pa;
             php[q] = pb;
-            double2 Za, Zb;
+            C2 Za, Zb;
             merge_pair(A, B, split_tw(tw.s, m, pr == 0), Za, Zb);
             lds[lds_pad(pe)] = Za;
             lds[lds_pad(q)] = Zb;
@@ -476,15 +486,15 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
 #endif
         }
         if (tid == 0) {  // DC and Nyquist: only the real parts enter the C2R transform
-            double p0 = php[0], pm = php[M];
-            const double2 A = synthesize_bin(p, mg0, ic0, p0);
-            const double2 B = synthesize_bin(p, mgm, icm, pm);
+            R p0 = php[0], pm = php[M];
+            const C2 A = synthesize_bin(p, mg0, ic0, p0);
+            const C2 B = synthesize_bin(p, mgm, icm, pm);
             php[0] = p0;
             php[M] = pm;
-            lds[lds_pad(0)] = make_double2(A.x - B.x, A.x + B.x);
+            lds[lds_pad(0)] = mk2(A.x - B.x, A.x + B.x);
         }
         __syncthreads();
-        double2 v[8];
+        C2 v[8];
         load8<LOG2M>(lds, lt, v);
         dft<8>(v);
         fft_after_first<LOG2M>(lds, tw, lt, v, [&]() {
@@ -494,32 +504,32 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
         const bool emit = f >= f0;
         if (OLA) {
             // W == N (off = 0): window samples 2i, 2i+1 pair with complex element (i + M/2) mod M
-            double2 wv[NP], zv[NP];
+            C2 wv[NP], zv[NP];
 #pragma unroll
-            for (int j = 0; j < NP; ++j) wv[j] = reinterpret_cast<const double2 *>(p.window)[(unsigned)(lt + j * T)];
+            for (int j = 0; j < NP; ++j) wv[j] = reinterpret_cast<const C2 *>(p.window)[(unsigned)(lt + j * T)];
 #pragma unroll
             for (int j = 0; j < NP; ++j) zv[j] = lds[lds_pad((lt + j * T + M / 2) & (M - 1))];
-            double2 cur[NP];
+            C2 cur[NP];
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
-                const double2 old = j < NK ? tail[j] : make_double2(0.0, 0.0);
+                const C2 old = j < NK ? tail[j] : mk2((R)0, (R)0);
                 cur[j].x = old.x + wv[j].x * (zv[j].y * p.inv_n);
                 cur[j].y = old.y + wv[j].y * (zv[j].x * p.inv_n);
             }
             if (emit) {
-                double2 *yc = reinterpret_cast<double2 *>(a.out + c * a.out_stride + f * p.H);
+                C2 *yc = reinterpret_cast<C2 *>(a.out + c * a.out_stride + f * p.H);
 #pragma unroll
                 for (int j = 0; j < NHP; ++j) yc[(unsigned)(lt + j * T)] = cur[j];
             }
 #pragma unroll
             for (int j = 0; j < NK; ++j) tail[j] = cur[j + NHP];
         } else {
-            double *fo = a.out + row * p.W;
+            R *fo = a.out + row * p.W;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int i = lt + j * T;
                 const int n = (i + p.off + M) & (N - 1);
-                const double s = ldsd[2 * lds_pad(n >> 1) + ((n & 1) ^ 1)] * p.inv_n;
+                const R s = ldsd[2 * lds_pad(n >> 1) + ((n & 1) ^ 1)] * p.inv_n;
                 if (i < p.W) fo[(unsigned)i] = p.window[(unsigned)i] * s;
             }
         }
@@ -527,12 +537,12 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
     }
 
     if (f1 == a.F && f1 > f0) {
-        double *po = a.phase_out + c * p.K;
+        R *po = a.phase_out + c * p.K;
         for (int k = tid; k < p.K; k += T) po[k] = php[k];  // php is stable: last barrier passed
         if (OLA) {
             // tail after the last frame: the remaining N - H partial sums, then the zero padding of
             // the last chunk (sumFramesE, Frames.hs:45-47)
-            double *yc = a.out + c * a.out_stride;
+            R *yc = a.out + c * a.out_stride;
             const long long start = a.F * p.H;
 #pragma unroll
             for (int j = 0; j < NK; ++j) {
@@ -540,7 +550,7 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
                 if (pos < a.out_len) yc[pos] = tail[j].x;
                 if (pos + 1 < a.out_len) yc[pos + 1] = tail[j].y;
             }
-            for (long long pos = start + 2 * NK * T + tid; pos < a.out_len; pos += T) yc[pos] = 0.0;
+            for (long long pos = start + 2 * NK * T + tid; pos < a.out_len; pos += T) yc[pos] = (R)0;
         }
     }
 }

@@ -184,13 +184,14 @@ void launch_synthesis(voc_ctx *c, const voc::SynArgsT<R> &a, long long channels,
 inline bool fast_sizes(const voc_ctx *c) { return !c->force_generic && c->log2m >= 9 && c->log2m <= 12; }
 
 // Specialised analysis kernel (polar output) when the frame length allows it.
-bool launch_analysis_fast(voc_ctx *c, const voc::AnaArgs &a, long long channels, hipStream_t st)
+template <class R>
+bool launch_analysis_fast(voc_ctx *c, const voc::AnaArgsT<R> &a, long long channels, hipStream_t st)
 {
     if (!fast_sizes(c)) return false;
     const long long grid = channels * a.tiles;
     if (grid <= 0) return true;
     if (grid > 0x7fffffffLL) throw HipFail{hipErrorInvalidValue, "analysis grid too large"};
-    const bool vec2 = c->W == c->N && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0) && a.chan_stride % 2 == 0 &&
+    const bool vec2 = c->W == c->N && (reinterpret_cast<uintptr_t>(a.x) % (2 * sizeof(R)) == 0) && a.chan_stride % 2 == 0 &&
                       a.frame_stride % 2 == 0;
     // frames cut from one signal, hop a multiple of 2T: the sample window slides in registers
     const int t2 = 2 * (c->M / 8);
@@ -205,12 +206,12 @@ bool launch_analysis_fast(voc_ctx *c, const voc::AnaArgs &a, long long channels,
 #define X(L)                                                                                                        \
     case L: {                                                                                                       \
         const dim3 b(voc::FastCfg<L>::T);                                                                           \
-        const size_t lds = voc::FastCfg<L>::LDS_BYTES;                                                              \
-        if (!vec2) hipLaunchKernelGGL((voc::analysis_fast_kernel<L, false, 0>), g, b, lds, st, c->params, a);       \
-        else if (slide == 1) hipLaunchKernelGGL((voc::analysis_fast_kernel<L, true, 1>), g, b, lds, st, c->params, a); \
-        else if (slide == 2) hipLaunchKernelGGL((voc::analysis_fast_kernel<L, true, 2>), g, b, lds, st, c->params, a); \
-        else if (slide == 4) hipLaunchKernelGGL((voc::analysis_fast_kernel<L, true, 4>), g, b, lds, st, c->params, a); \
-        else hipLaunchKernelGGL((voc::analysis_fast_kernel<L, true, 0>), g, b, lds, st, c->params, a);              \
+        const size_t lds = voc::FastCfg<L>::template lds_bytes<R>();                                                \
+        if (!vec2) hipLaunchKernelGGL((voc::analysis_fast_kernel<L, false, 0, R>), g, b, lds, st, params_of<R>(c), a);       \
+        else if (slide == 1) hipLaunchKernelGGL((voc::analysis_fast_kernel<L, true, 1, R>), g, b, lds, st, params_of<R>(c), a); \
+        else if (slide == 2) hipLaunchKernelGGL((voc::analysis_fast_kernel<L, true, 2, R>), g, b, lds, st, params_of<R>(c), a); \
+        else if (slide == 4) hipLaunchKernelGGL((voc::analysis_fast_kernel<L, true, 4, R>), g, b, lds, st, params_of<R>(c), a); \
+        else hipLaunchKernelGGL((voc::analysis_fast_kernel<L, true, 0, R>), g, b, lds, st, params_of<R>(c), a);              \
     } break;
         VOC_FOR_EACH_FAST_LOG2M(X)
 #undef X
@@ -221,31 +222,33 @@ bool launch_analysis_fast(voc_ctx *c, const voc::AnaArgs &a, long long channels,
 
 // The register-resident overlap-add needs W == N (eight sample pairs per thread), a hop that is a
 // multiple of twice the thread count, and 16-byte aligned output rows.  Returns H / 2T or 0.
-inline int fast_ola_nhp(const voc_ctx *c, const voc::SynArgs &a)
+template <class R>
+inline int fast_ola_nhp(const voc_ctx *c, const voc::SynArgsT<R> &a)
 {
     if (!fast_sizes(c) || c->W != c->N) return 0;
     const int t2 = 2 * (c->M / 8);
     if (c->H % t2 != 0) return 0;
-    if (reinterpret_cast<uintptr_t>(a.out) % 16 != 0 || a.out_stride % 2 != 0) return 0;
+    if (reinterpret_cast<uintptr_t>(a.out) % (2 * sizeof(R)) != 0 || a.out_stride % 2 != 0) return 0;
     const int nhp = c->H / t2;
     return (nhp == 1 || nhp == 2 || nhp == 4 || nhp == 8) ? nhp : 0;
 }
 
-template <int L, bool OLA>
-void launch_synthesis_fast_nh(voc_ctx *c, const voc::SynArgs &a, unsigned grid, int nhp, hipStream_t st)
+template <int L, bool OLA, class R>
+void launch_synthesis_fast_nh(voc_ctx *c, const voc::SynArgsT<R> &a, unsigned grid, int nhp, hipStream_t st)
 {
     const dim3 g(grid), b(voc::FastCfg<L>::T);
-    const size_t lds = voc::FastCfg<L>::LDS_BYTES;
+    const size_t lds = voc::FastCfg<L>::template lds_bytes<R>();
     switch (nhp) {
-    case 1: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 1>), g, b, lds, st, c->params, a); break;
-    case 2: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 2>), g, b, lds, st, c->params, a); break;
-    case 4: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 4>), g, b, lds, st, c->params, a); break;
-    default: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 8>), g, b, lds, st, c->params, a); break;
+    case 1: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 1, R>), g, b, lds, st, params_of<R>(c), a); break;
+    case 2: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 2, R>), g, b, lds, st, params_of<R>(c), a); break;
+    case 4: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 4, R>), g, b, lds, st, params_of<R>(c), a); break;
+    default: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 8, R>), g, b, lds, st, params_of<R>(c), a); break;
     }
 }
 
 // Specialised synthesis kernel (polar input): frames out, or overlap-add out when fast_ola_nhp() != 0.
-bool launch_synthesis_fast(voc_ctx *c, const voc::SynArgs &a, long long channels, bool ola, hipStream_t st)
+template <class R>
+bool launch_synthesis_fast(voc_ctx *c, const voc::SynArgsT<R> &a, long long channels, bool ola, hipStream_t st)
 {
     if (!fast_sizes(c)) return false;
     const int nh = ola ? fast_ola_nhp(c, a) : 8;
@@ -257,9 +260,9 @@ bool launch_synthesis_fast(voc_ctx *c, const voc::SynArgs &a, long long channels
     switch (c->log2m) {
 #define X(L)                                                                          \
     case L:                                                                           \
-        if (ola) launch_synthesis_fast_nh<L, true>(c, a, (unsigned)grid, nh, st);     \
-        else hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, false, 8>), dim3((unsigned)grid), \
-                                dim3(voc::FastCfg<L>::T), voc::FastCfg<L>::LDS_BYTES, st, c->params, a); \
+        if (ola) launch_synthesis_fast_nh<L, true, R>(c, a, (unsigned)grid, nh, st);     \
+        else hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, false, 8, R>), dim3((unsigned)grid), \
+                                dim3(voc::FastCfg<L>::T), voc::FastCfg<L>::template lds_bytes<R>(), st, params_of<R>(c), a); \
         break;
         VOC_FOR_EACH_FAST_LOG2M(X)
 #undef X
@@ -577,8 +580,7 @@ void roundtrip_dev(voc_ctx *c, const R *x, long long x_stride, long long len, lo
         a.tile_len = r.ana_tile;
         a.tiles = r.ana_tiles;
         a.vol = (R)c->vol;  // volumeFix folded into the magnitude store (Conduit.hs:34-35)
-        bool done = false;
-        if constexpr (std::is_same<R, double>::value) done = launch_analysis_fast(c, a, G, st);
+        bool done = launch_analysis_fast<R>(c, a, G, st);
         if (!done) launch_analysis<false, false, R>(c, a, G, st);
 
         if (r.syn_tiles > 1) {
@@ -603,14 +605,12 @@ void roundtrip_dev(voc_ctx *c, const R *x, long long x_stride, long long len, lo
         s.tiles = r.syn_tiles;
         s.halo = r.halo;
         if (r.fused_ola) {
-            done = false;
-            if constexpr (std::is_same<R, double>::value) done = launch_synthesis_fast(c, s, G, true, st);
+            done = launch_synthesis_fast<R>(c, s, G, true, st);
             if (!done) launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_OLA, R>(c, s, G, st);
         } else {
             // frame too long for an LDS-resident overlap-add ring: frames go through HBM once
             s.out = frames;
-            done = false;
-            if constexpr (std::is_same<R, double>::value) done = launch_synthesis_fast(c, s, G, false, st);
+            done = launch_synthesis_fast<R>(c, s, G, false, st);
             if (!done) launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_FRAMES, R>(c, s, G, st);
             const long long total = G * r.out_len;
             hipLaunchKernelGGL(voc::sum_frames_kernel<R>, dim3(ew_grid(total)), dim3(256), 0, st, (const R *)frames, F, c->W, c->H,
