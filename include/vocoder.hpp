@@ -6,6 +6,7 @@
 // failing call throws std::runtime_error where the reference calls `error` (Vocoder.hs:132).
 #pragma once
 
+#include <cstdint>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -109,5 +110,90 @@ inline Processed process(const VocoderParams &par, const std::vector<double> &x,
           "process", par.handle());
     return r;
 }
+
+
+// Vocoder.Filter (vocoder/src/Vocoder/Filter.hs): a chain in composeFilters order.
+class Filter {
+public:
+    Filter(const VocoderParams &par, double freq_step) : par_(par)
+    {
+        check(voc_filter_create(par.handle(), freq_step, &f_), "filter", par.handle());
+    }
+    ~Filter() { voc_filter_destroy(f_); }
+    Filter(const Filter &) = delete;
+    Filter &operator=(const Filter &) = delete;
+
+    Filter &append(int32_t kind, const std::vector<double> &params)
+    {
+        check(voc_filter_append(f_, kind, params.data(), (int32_t)params.size()), "filter", par_.handle());
+        return *this;
+    }
+    Filter &amplify(double k) { return append(VOC_FILTER_AMPLIFY, {k}); }                              // Filter.hs:80-81
+    Filter &lowpassBrickwall(double t) { return append(VOC_FILTER_LOWPASS_BRICKWALL, {t}); }           // Filter.hs:84-85
+    Filter &highpassBrickwall(double t) { return append(VOC_FILTER_HIGHPASS_BRICKWALL, {t}); }         // Filter.hs:88-89
+    Filter &bandpassBrickwall(double t, double u) { return append(VOC_FILTER_BANDPASS_BRICKWALL, {t, u}); }
+    Filter &bandstopBrickwall(double t, double u) { return append(VOC_FILTER_BANDSTOP_BRICKWALL, {t, u}); }
+    Filter &lowpassButterworth(double n, double t) { return append(VOC_FILTER_LOWPASS_BUTTERWORTH, {n, t}); }
+    Filter &highpassButterworth(double n, double t) { return append(VOC_FILTER_HIGHPASS_BUTTERWORTH, {n, t}); }
+    Filter &bandpassButterworth(double n, double t, double u) { return append(VOC_FILTER_BANDPASS_BUTTERWORTH, {n, t, u}); }
+    Filter &bandstopButterworth(double n, double t, double u) { return append(VOC_FILTER_BANDSTOP_BUTTERWORTH, {n, t, u}); }
+    Filter &pitchShiftInterpolate(double n) { return append(VOC_FILTER_PITCH_SHIFT_INTERPOLATE, {n}); }  // Filter.hs:128-129
+    Filter &convolutionFilter(const std::vector<double> &ker) { return append(VOC_FILTER_CONVOLUTION, ker); }
+    Filter &envelopeFilter(int ksize) { return append(VOC_FILTER_ENVELOPE, {(double)ksize}); }        // Filter.hs:151-152
+    Filter &randomPhaseFilter(uint64_t seed) { return append(VOC_FILTER_RANDOM_PHASE, {(double)seed}); }
+
+    // runs the chain on F frames of one channel, in place
+    void apply(STFTFrames &stft) const
+    {
+        const size_t k = (size_t)par_.vocFreqFrameLength();
+        check(voc_filter_apply(f_, stft.mag.data(), stft.ph_inc.data(), (int64_t)(stft.mag.size() / k), 1), "filter",
+              par_.handle());
+    }
+    voc_filter *handle() const { return f_; }
+
+private:
+    const VocoderParams &par_;
+    voc_filter *f_ = nullptr;
+};
+
+// Vocoder.Conduit.process fed chunk by chunk (Conduit.hs:46-53): push returns what sumFramesE has
+// published so far, flush the rest.
+class Stream {
+public:
+    Stream(const VocoderParams &par, int64_t channels, int64_t chunk, const Filter *filter = nullptr, bool dunai = false)
+        : par_(par), channels_(channels)
+    {
+        check(voc_stream_create_mode(par.handle(), channels, chunk, filter ? filter->handle() : nullptr,
+                                     dunai ? VOC_STREAM_DUNAI : VOC_STREAM_CONDUIT, &s_),
+              "stream", par.handle());
+    }
+    ~Stream() { voc_stream_destroy(s_); }
+    Stream(const Stream &) = delete;
+    Stream &operator=(const Stream &) = delete;
+
+    // x: channels x n planar; returns channels x m planar
+    std::vector<double> push(const std::vector<double> &x)
+    {
+        const int64_t n = channels_ ? (int64_t)x.size() / channels_ : 0;
+        const int64_t m = voc_stream_push_length(s_, n);
+        std::vector<double> y((size_t)(channels_ * (m > 0 ? m : 0)));
+        int64_t got = 0;
+        check(voc_stream_push(s_, x.data(), n, n, y.data(), m, m, &got), "stream push", par_.handle());
+        return y;
+    }
+    std::vector<double> flush()
+    {
+        const int64_t m = voc_stream_flush_length(s_);
+        std::vector<double> y((size_t)(channels_ * (m > 0 ? m : 0)));
+        int64_t got = 0;
+        check(voc_stream_flush(s_, y.data(), m, m, &got), "stream flush", par_.handle());
+        return y;
+    }
+
+private:
+    const VocoderParams &par_;
+    int64_t channels_;
+    voc_stream *s_ = nullptr;
+};
 
 }  // namespace vocoder
