@@ -122,7 +122,8 @@ def main():
         names = ("analysis_kernel", "phase_carry_kernel", "synthesis_kernel")
         avg = [ms[0][i] / ms[1][i] if ms[1][i] else 0.0 for i in range(3)]     # ms per launch
         dom = 0 if avg[0] >= avg[2] else 2
-        alg = (BYTES_ANALYSIS, 0, BYTES_SYNTHESIS)[dom] * frames               # bytes one launch moves
+        # bytes one launch moves: the library may cut a step's frames into several launches of a kernel
+        alg = (BYTES_ANALYSIS, 0, BYTES_SYNTHESIS)[dom] * frames * args.steps / max(int(ms[1][dom]), 1)
         achieved = alg / (avg[dom] * 1e-3) / 1e9 if avg[dom] else 0.0
         out = {
             "metric": "STFT frames/sec analysis+synthesis (N=4096,hop=1024,fp64); % HBM roofline",
@@ -134,6 +135,7 @@ def main():
                        "streams_per_gpu": c, "frames_per_step_per_gpu": frames, "sharding": "by stream, no collective"},
             "hbm_roofline_frac_whole_path": value / world * BYTES_FRAME / HBM_PEAK,
             "kernel_ms": {names[i]: avg[i] for i in range(3) if ms[1][i]},
+            "kernel_launches_per_step": {names[i]: int(ms[1][i]) // args.steps for i in range(3) if ms[1][i]},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9), "traffic": None},
         }
