@@ -17,7 +17,8 @@
  *     {re, im} (16 bytes), the layout of Haskell's `Storable (Complex Double)`.
  *   - N = FFT frame length (vocFrameLength), W = window / input frame length
  *     (vocInputFrameLength, W <= N), H = hop (vocHopSize), K = N/2+1
- *     (vocFreqFrameLength).  This build supports N = 2^m, 8 <= N <= 16384.
+ *     (vocFreqFrameLength).  This build supports N = 2^m, 8 <= N <= 16384,
+ *     and every other N in [2, 4096] (chirp-z transform; double precision only).
  *   - the caller owns every buffer; the library owns only the opaque voc_ctx.
  *   - entry points without a `_dev` suffix take HOST pointers and copy through
  *     device memory they allocate; `_dev` entry points take DEVICE pointers and
@@ -40,7 +41,7 @@ typedef struct voc_ctx voc_ctx;
 enum {
     VOC_OK = 0,
     VOC_ERR_INVALID = -1,     /* NULL pointer, negative count, W > N (Vocoder.hs:132), H < 1 */
-    VOC_ERR_UNSUPPORTED = -2, /* frame length not a supported power of two, unknown precision */
+    VOC_ERR_UNSUPPORTED = -2, /* frame length out of range (see above), unknown precision */
     VOC_ERR_HIP = -3,         /* a HIP runtime call failed; see voc_last_hip_error() */
     VOC_ERR_NOMEM = -4,       /* device or host allocation failed */
     VOC_ERR_SIZE = -5,        /* buffer / workspace too small, size mismatch (vector-fftw `execute`) */

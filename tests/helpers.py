@@ -45,13 +45,14 @@ def check_fft_layer(lib, orc, n, w, h, rng, batch=3):
     spec = V.fft_execute_r2c(par, x)
     ref = np.stack([orc.fft_r2c(r) for r in x])
     assert rel_l2(spec, ref) <= TOL_L2
-    assert np.all(spec[:, 0].imag == 0) and np.all(spec[:, -1].imag == 0)
+    assert np.all(spec[:, 0].imag == 0) and (n % 2 == 1 or np.all(spec[:, -1].imag == 0))
     back = V.fft_execute_c2r(par, ref)
     assert rel_l2(back, np.stack([orc.fft_c2r(s, n) for s in ref])) <= TOL_L2
     # imaginary parts of DC / Nyquist are ignored by C2R
     dirty = ref.copy()
     dirty[:, 0] += 3j
-    dirty[:, -1] -= 2j
+    if n % 2 == 0:          # an odd length has no Nyquist bin: its last bin is an ordinary complex one
+        dirty[:, -1] -= 2j
     assert rel_l2(V.fft_execute_c2r(par, dirty), back) <= 1e-15
     fr = rng.standard_normal((batch, w))
     s2 = V.do_fft(par, fr)

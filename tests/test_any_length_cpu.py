@@ -1,0 +1,42 @@
+"""Frame lengths that are not powers of two (chirp-z path) on CPU, host-emulated kernels against
+the oracle, whose FFT for such lengths is a long double DFT."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import helpers as Hh  # noqa: E402
+
+SIZES = [(3, 3, 1), (7, 7, 2), (12, 12, 3), (15, 11, 4), (100, 81, 20), (250, 250, 50), (1000, 1000, 250)]
+
+
+@pytest.mark.parametrize("n,w,h", SIZES)
+def test_fft_layer_any_length(emu_lib, orc, n, w, h):
+    Hh.check_fft_layer(emu_lib, orc, n, w, h, np.random.default_rng(n))
+
+
+@pytest.mark.parametrize("n,w,h", SIZES)
+def test_stages_and_roundtrip_any_length(emu_lib, orc, n, w, h):
+    rng = np.random.default_rng(n + 1)
+    Hh.check_stages(emu_lib, orc, n, w, h, 7, 2, rng, ana_tile=3, syn_tile=4)
+    Hh.check_roundtrip(emu_lib, orc, n, w, h, w + h * 9 + 5, 2, rng, ana_tile=4, syn_tile=3)
+
+
+def test_filters_and_stream_on_a_non_power_of_two_length(emu_lib, orc):
+    from vocoder_amd import vocoder as V, conduit as Cd, stream as S, filter as Fl
+    n, h = 100, 25
+    win = orc.make_window("hann", n)
+    par = V.VocoderParams(n, h, win, lib=emu_lib)
+    rng = np.random.default_rng(3)
+    mag, inc = rng.uniform(0, 1, (2, 4, par.K)), rng.uniform(-1, 1, (2, 4, par.K))
+    chain = Fl.pitch_shift_interpolate(1.5) >> Fl.lowpass_butterworth(2.0, 5000.0) >> Fl.envelope_filter(5)
+    m, i = chain.bind(par, 480.0).apply(mag, inc)
+    mo, io = orc.apply_filter(480.0, [("pitch_shift", 1.5), ("lowpass_butterworth", 2.0, 5000.0), ("envelope", 5)], mag, inc)
+    assert np.allclose(m, mo, rtol=1e-12, atol=1e-15) and np.array_equal(i, io)
+    x = rng.standard_normal((1, n + h * 13 + 2))
+    y_ref = Cd.process_with(par, x)[0]
+    st = S.Stream(par, 1)
+    y = np.concatenate([st.push(x[:, :77]), st.push(x[:, 77:]), st.flush()], axis=1)
+    assert np.array_equal(y, y_ref)

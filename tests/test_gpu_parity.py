@@ -214,3 +214,14 @@ def test_device_entry_matches_host_entry_and_runs_the_native_library(gpu_lib, or
     par.close()
     loaded = open("/proc/self/maps").read()
     assert "libvocoder_hip.so" in loaded and "libvocoder_emu" not in loaded and "libvocoder_oracle" in loaded
+
+
+@pytest.mark.parametrize("n,w,h", [(1000, 1000, 250), (1500, 1200, 300), (3000, 3000, 750), (4093, 4093, 1023),
+                                   (4095, 3001, 1000), (12, 12, 3), (7, 5, 2)])
+def test_lengths_that_are_not_powers_of_two(gpu_lib, orc, n, w, h):
+    """The chirp-z path (any frame length up to 4096, as FFTW accepts) against the oracle's long
+    double DFT."""
+    rng = np.random.default_rng(n)
+    Hh.check_fft_layer(gpu_lib, orc, n, w, h, rng)
+    Hh.check_stages(gpu_lib, orc, n, w, h, 5, 2, rng)
+    Hh.check_roundtrip(gpu_lib, orc, n, w, h, w + h * 7 + 3, 2, rng)

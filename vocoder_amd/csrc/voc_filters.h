@@ -108,7 +108,8 @@ __global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p
                                                                         long long rows)
 {
     using Cf = FiltCfg<LOG2M>;
-    constexpr int T = Cf::T, NE = Cf::NE, K = Cf::M + 1;
+    constexpr int T = Cf::T, NE = Cf::NE;
+    const int K = p.K;  // at most M + 1 (M + 1 for power-of-two frame lengths)
     VOC_SMEM(double, lds);
     double *lm = lds, *li = lds + ((K + 1) & ~1);
     const int tid = threadIdx.x;

@@ -5,6 +5,7 @@
 #endif
 
 #include <cmath>
+#include <complex>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +20,7 @@
 #include "voc_kernels.h"
 #include "voc_kernels_fast.h"
 #include "voc_filters.h"
+#include "voc_kernels_bluestein.h"
 
 #define VOC_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -30,6 +32,11 @@ struct voc_ctx {
     double2 *d_twP = nullptr, *d_twS = nullptr;
     voc::Params params{};
     int precision = VOC_PRECISION_F64;
+    // frame lengths that are not powers of two: chirp-z transform over an L-point FFT (M and log2m
+    // then describe L, not N/2)
+    bool bluestein = false;
+    double2 *d_chirp = nullptr, *d_bfft = nullptr;
+    voc::BlueTab blue{};
     // single-precision contexts: float copies of the tables (the double ones stay for the accessors)
     float *d_window_f = nullptr;
     float2 *d_twP_f = nullptr, *d_twS_f = nullptr;
@@ -140,6 +147,7 @@ template <> const voc::ParamsT<double> &params_of<double>(const voc_ctx *c) { re
 template <> const voc::ParamsT<float> &params_of<float>(const voc_ctx *c) { return c->params_f; }
 
 #define VOC_FOR_EACH_LOG2M(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
+#define VOC_FOR_EACH_BLUE_LOG2L(X) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
 
 template <bool RAW, bool SPEC, class R = double>
 void launch_analysis(voc_ctx *c, const voc::AnaArgsT<R> &a, long long channels, hipStream_t st)
@@ -148,6 +156,23 @@ void launch_analysis(voc_ctx *c, const voc::AnaArgsT<R> &a, long long channels, 
     if (grid <= 0) return;
     if (grid > 0x7fffffffLL) throw HipFail{hipErrorInvalidValue, "analysis grid too large"};
     LaunchTimer timer(c, SPEC ? KIND_OTHER : KIND_ANALYSIS, st);
+    if (c->bluestein) {
+        if constexpr (std::is_same<R, double>::value) {
+            switch (c->log2m) {
+#define X(L)                                                                                              \
+    case L:                                                                                               \
+        hipLaunchKernelGGL((voc::analysis_blue_kernel<L, RAW, SPEC>), dim3((unsigned)grid), dim3(voc::Cfg<L>::T), \
+                           lds_bytes<double>(c, false), st, c->params, a, c->blue);                       \
+        break;
+                VOC_FOR_EACH_BLUE_LOG2L(X)
+#undef X
+            }
+            HIPCHK(hipGetLastError());
+            return;
+        } else {
+            throw StatusFail{VOC_ERR_UNSUPPORTED};
+        }
+    }
     switch (c->log2m) {
 #define X(L)                                                                                              \
     case L:                                                                                               \
@@ -167,6 +192,23 @@ void launch_synthesis(voc_ctx *c, const voc::SynArgsT<R> &a, long long channels,
     if (grid <= 0) return;
     if (grid > 0x7fffffffLL) throw HipFail{hipErrorInvalidValue, "synthesis grid too large"};
     LaunchTimer timer(c, IN_MODE == voc::SYN_IN_SPEC ? KIND_OTHER : KIND_SYNTHESIS, st);
+    if (c->bluestein) {
+        if constexpr (std::is_same<R, double>::value && OUT_MODE != voc::SYN_OUT_OLA) {
+            switch (c->log2m) {
+#define X(L)                                                                                              \
+    case L:                                                                                               \
+        hipLaunchKernelGGL((voc::synthesis_blue_kernel<L, IN_MODE, OUT_MODE>), dim3((unsigned)grid),      \
+                           dim3(voc::Cfg<L>::T), lds_bytes<double>(c, false), st, c->params, a, c->blue); \
+        break;
+                VOC_FOR_EACH_BLUE_LOG2L(X)
+#undef X
+            }
+            HIPCHK(hipGetLastError());
+            return;
+        } else {
+            throw StatusFail{VOC_ERR_UNSUPPORTED};  // overlap-add of these lengths goes through frames
+        }
+    }
     switch (c->log2m) {
 #define X(L)                                                                                                    \
     case L:                                                                                                     \
@@ -181,7 +223,7 @@ void launch_synthesis(voc_ctx *c, const voc::SynArgsT<R> &a, long long channels,
 
 #define VOC_FOR_EACH_FAST_LOG2M(X) X(9) X(10) X(11) X(12)
 
-inline bool fast_sizes(const voc_ctx *c) { return !c->force_generic && c->log2m >= 9 && c->log2m <= 12; }
+inline bool fast_sizes(const voc_ctx *c) { return !c->force_generic && !c->bluestein && c->log2m >= 9 && c->log2m <= 12; }
 
 // Specialised analysis kernel (polar output) when the frame length allows it.
 template <class R>
@@ -438,7 +480,7 @@ void synthesis_signal_dev(voc_ctx *c, const double *mag, const double *inc, long
                           double *phase_io, double *y, long long y_stride, long long y_len, hipStream_t st)
 {
     if (C <= 0 || F <= 0) return;
-    const bool fused = lds_bytes(c, true) <= kLdsLimit;
+    const bool fused = !c->bluestein && lds_bytes(c, true) <= kLdsLimit;
     const int halo = fused ? (c->W + c->H - 1) / c->H - 1 : 0;
     int tile_len, tiles;
     synthesis_tiling(c, C, F, halo, &tile_len, &tiles);
@@ -508,7 +550,7 @@ RtPlan roundtrip_plan(const voc_ctx *c, long long len, long long group, long lon
     r.out_len = ola_length(c, r.F, chunk > 0 ? chunk : c->H);
     r.ldk = (c->K + 1) & ~1LL;
     const bool f32 = c->precision == VOC_PRECISION_F32;
-    r.fused_ola = (f32 ? lds_bytes<float>(c, true) : lds_bytes<double>(c, true)) <= kLdsLimit;
+    r.fused_ola = !c->bluestein && (f32 ? lds_bytes<float>(c, true) : lds_bytes<double>(c, true)) <= kLdsLimit;
     r.halo = r.fused_ola ? (c->W + c->H - 1) / c->H - 1 : 0;
     if (r.F > 0) {
         r.ana_tile = analysis_tile_len(c, group, r.F);
@@ -639,7 +681,7 @@ VOC_EXPORT const char *voc_strerror(int32_t s)
     switch (s) {
     case VOC_OK: return "ok";
     case VOC_ERR_INVALID: return "invalid argument";
-    case VOC_ERR_UNSUPPORTED: return "unsupported frame length or precision (frame length must be a power of two in [8, 16384])";
+    case VOC_ERR_UNSUPPORTED: return "unsupported frame length or precision (frame length: a power of two up to 16384, or any length up to 4096)";
     case VOC_ERR_HIP: return "HIP runtime call failed";
     case VOC_ERR_NOMEM: return "out of memory";
     case VOC_ERR_SIZE: return "size mismatch";
@@ -658,7 +700,9 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
     if (!window || W < 1 || H < 1 || N < 1) return VOC_ERR_INVALID;
     if (W > N) return VOC_ERR_INVALID;  // addZeroPadding: input longer than target length (Vocoder.hs:132)
     if (precision != VOC_PRECISION_F64 && precision != VOC_PRECISION_F32) return VOC_ERR_UNSUPPORTED;
-    if (N < 8 || N > 16384 || (N & (N - 1)) != 0) return VOC_ERR_UNSUPPORTED;
+    const bool pow2 = N >= 8 && N <= 16384 && (N & (N - 1)) == 0;
+    const bool chirp = !pow2 && N >= 2 && N <= 4096 && precision == VOC_PRECISION_F64;
+    if (!pow2 && !chirp) return VOC_ERR_UNSUPPORTED;
     voc_ctx *c = new (std::nothrow) voc_ctx;
     if (!c) return VOC_ERR_NOMEM;
     int32_t rc = guarded(c, [&]() -> int32_t {
@@ -667,6 +711,11 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
         if (device < 0 || device >= ndev) return VOC_ERR_INVALID;
         HIPCHK(hipSetDevice(device));
         c->N = N; c->W = W; c->H = H; c->K = N / 2 + 1; c->M = N / 2; c->device = device;
+        c->bluestein = chirp;
+        if (chirp) {  // the FFT underneath has L = 2^m >= 2N - 1 complex points
+            c->M = 8;
+            while (c->M < 2 * N - 1) c->M *= 2;
+        }
         c->precision = precision;
         c->log2m = 0;
         while ((1 << c->log2m) < c->M) ++c->log2m;
@@ -718,6 +767,47 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
         p.window = c->d_window;
         p.twP = c->d_twP;
         p.twS = c->d_twS;
+        if (chirp) {
+            const int L = c->M;
+            const long double pi_l = 3.141592653589793238462643383279502884L;
+            std::vector<double2> w((size_t)N);
+            std::vector<std::complex<long double>> bl((size_t)L, std::complex<long double>(0.0L, 0.0L));
+            for (int n = 0; n < N; ++n) {
+                const long long r = ((long long)n * n) % (2LL * N);  // n^2 mod 2N keeps the angle small
+                const long double ang = pi_l * (long double)r / (long double)N;
+                const std::complex<long double> v(cosl(ang), sinl(ang));
+                w[n] = make_double2((double)v.real(), (double)v.imag());
+                bl[n] = v;
+                if (n > 0) bl[L - n] = v;
+            }
+            // FFT of b in long double (iterative radix 2)
+            for (int i = 1, j = 0; i < L; ++i) {
+                int bit = L >> 1;
+                for (; j & bit; bit >>= 1) j ^= bit;
+                j ^= bit;
+                if (i < j) std::swap(bl[i], bl[j]);
+            }
+            for (int len = 2; len <= L; len <<= 1) {
+                for (int i = 0; i < L; i += len)
+                    for (int k = 0; k < len / 2; ++k) {
+                        const long double ang = -2.0L * pi_l * (long double)k / (long double)len;
+                        const std::complex<long double> t = std::complex<long double>(cosl(ang), sinl(ang)) * bl[i + k + len / 2];
+                        const std::complex<long double> u = bl[i + k];
+                        bl[i + k] = u + t;
+                        bl[i + k + len / 2] = u - t;
+                    }
+            }
+            std::vector<double2> bf((size_t)L);
+            for (int m = 0; m < L; ++m) bf[m] = make_double2((double)bl[m].real(), (double)bl[m].imag());
+            HIPCHK(hipMalloc((void **)&c->d_chirp, sizeof(double2) * w.size()));
+            HIPCHK(hipMalloc((void **)&c->d_bfft, sizeof(double2) * bf.size()));
+            HIPCHK(hipMemcpy(c->d_chirp, w.data(), sizeof(double2) * w.size(), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(c->d_bfft, bf.data(), sizeof(double2) * bf.size(), hipMemcpyHostToDevice));
+            c->blue.chirp = c->d_chirp;
+            c->blue.bfft = c->d_bfft;
+            c->blue.inv_l = 1.0 / (double)L;
+            c->blue.n_d = (double)N;
+        }
         if (precision == VOC_PRECISION_F32) {
             // the same tables rounded once to float (twiddles from the long double values, not from the doubles)
             std::vector<float> wf(window, window + W);
@@ -771,6 +861,8 @@ VOC_EXPORT int32_t voc_ctx_destroy(voc_ctx *c)
     if (c->d_window) (void)hipFree(c->d_window);
     if (c->d_twP) (void)hipFree(c->d_twP);
     if (c->d_twS) (void)hipFree(c->d_twS);
+    if (c->d_chirp) (void)hipFree(c->d_chirp);
+    if (c->d_bfft) (void)hipFree(c->d_bfft);
     if (c->d_window_f) (void)hipFree(c->d_window_f);
     if (c->d_twP_f) (void)hipFree(c->d_twP_f);
     if (c->d_twS_f) (void)hipFree(c->d_twS_f);
