@@ -1,0 +1,108 @@
+// asan_check.cpp -- DEVELOPMENT HARNESS: the C-ABI library compiled for the host (hip_emu.h) into one
+// executable under AddressSanitizer / UBSan, driven through a set of scenarios that cover every
+// kernel family (radix kernels, fast kernels, chirp-z, filters, streaming, single precision).
+//   make -C tools/emu asan && tools/emu/asan_check
+#include "../../vocoder_amd/csrc/vocoder_hip.cpp"
+
+#include <cstdio>
+#include <random>
+
+static std::vector<double> hann(int n)
+{
+    std::vector<double> w(n);
+    for (int i = 0; i < n; ++i) w[i] = 0.5 * (1 - std::cos(2 * M_PI * i / n));
+    return w;
+}
+
+#define OK(call)                                                                  \
+    do {                                                                          \
+        int32_t st_ = (call);                                                     \
+        if (st_ != 0) { std::printf("FAILED %s -> %d\n", #call, (int)st_); return 1; } \
+    } while (0)
+
+static int scenario(int n, int w, int h, int channels, int frames, int chunk)
+{
+    std::mt19937_64 rng(n * 31 + w);
+    std::normal_distribution<double> g;
+    voc_ctx *ctx = nullptr;
+    const auto win = hann(w);
+    OK(voc_ctx_create(n, h, win.data(), w, 0, VOC_PRECISION_F64, &ctx));
+    const int64_t len = w + (int64_t)h * (frames - 1) + 3, k = voc_freq_frame_length(ctx);
+    std::vector<double> x((size_t)channels * len);
+    for (auto &v : x) v = g(rng);
+    const int64_t f = voc_num_frames(ctx, len), olen = voc_ola_length(ctx, f, chunk), keep = voc_leftover_length(ctx, len);
+    std::vector<double> y((size_t)channels * olen), left((size_t)channels * (keep ? keep : 1)), a((size_t)channels * k, 0.0),
+        s((size_t)channels * k, 0.0);
+    OK(voc_roundtrip(ctx, x.data(), len, len, channels, chunk, y.data(), olen, a.data(), s.data(), left.data(), keep));
+
+    // stage by stage + filters
+    std::vector<double> fr((size_t)channels * f * w), mag((size_t)channels * f * k), inc(mag.size()), ph((size_t)channels * k, 0.0);
+    OK(voc_frames_of(ctx, x.data(), len, len, channels, fr.data()));
+    OK(voc_analysis_stage(ctx, ph.data(), fr.data(), mag.data(), inc.data(), channels, f));
+    voc_filter *flt = nullptr;
+    OK(voc_filter_create(ctx, 48000.0 / n, &flt));
+    const double q1[] = {1.5}, q2[] = {2.0, 3000.0}, q3[] = {5.0}, q4[] = {11.0};
+    OK(voc_filter_append(flt, VOC_FILTER_PITCH_SHIFT_INTERPOLATE, q1, 1));
+    OK(voc_filter_append(flt, VOC_FILTER_LOWPASS_BUTTERWORTH, q2, 2));
+    OK(voc_filter_append(flt, VOC_FILTER_ENVELOPE, q3, 1));
+    OK(voc_filter_append(flt, VOC_FILTER_RANDOM_PHASE, q4, 1));
+    OK(voc_filter_apply(flt, mag.data(), inc.data(), f, channels));
+    std::fill(ph.begin(), ph.end(), 0.0);
+    OK(voc_synthesis_stage(ctx, ph.data(), mag.data(), inc.data(), fr.data(), channels, f));
+    OK(voc_sum_frames(ctx, fr.data(), f, channels, chunk, y.data(), olen));
+
+    // streaming in uneven pieces, with the filter, then flush
+    voc_stream *st = nullptr;
+    OK(voc_stream_create(ctx, channels, chunk, flt, &st));
+    std::vector<double> piece, out;
+    for (int64_t pos = 0; pos < len;) {
+        const int64_t m = std::min<int64_t>(len - pos, 1 + (int64_t)(rng() % (3 * h + 1)));
+        piece.assign((size_t)channels * m, 0.0);
+        for (int c = 0; c < channels; ++c) std::copy_n(&x[(size_t)c * len + pos], m, &piece[(size_t)c * m]);
+        const int64_t cap = voc_stream_push_length(st, m);
+        out.assign((size_t)channels * (cap > 0 ? cap : 1), 0.0);
+        int64_t got = 0;
+        OK(voc_stream_push(st, piece.data(), m, m, out.data(), cap, cap, &got));
+        pos += m;
+    }
+    const int64_t cap = voc_stream_flush_length(st);
+    out.assign((size_t)channels * (cap > 0 ? cap : 1), 0.0);
+    int64_t got = 0;
+    OK(voc_stream_flush(st, out.data(), cap, cap, &got));
+    OK(voc_stream_destroy(st));
+    OK(voc_filter_destroy(flt));
+    OK(voc_ctx_destroy(ctx));
+    std::printf("ok  N=%d W=%d H=%d C=%d F=%lld\n", n, w, h, channels, (long long)f);
+    return 0;
+}
+
+static int scenario_f32(int n, int h, int channels, int frames)
+{
+    voc_ctx *ctx = nullptr;
+    const auto win = hann(n);
+    OK(voc_ctx_create(n, h, win.data(), n, 0, VOC_PRECISION_F32, &ctx));
+    const int64_t len = n + (int64_t)h * (frames - 1) + 1, k = voc_freq_frame_length(ctx);
+    std::vector<float> x((size_t)channels * len, 0.25f);
+    const int64_t f = voc_num_frames(ctx, len), olen = voc_ola_length(ctx, f, h), keep = voc_leftover_length(ctx, len);
+    std::vector<float> y((size_t)channels * olen), left((size_t)channels * (keep ? keep : 1)), a((size_t)channels * k, 0.f),
+        s((size_t)channels * k, 0.f);
+    OK(voc_roundtrip_f32(ctx, x.data(), len, len, channels, h, y.data(), olen, a.data(), s.data(), left.data(), keep));
+    OK(voc_ctx_destroy(ctx));
+    std::printf("ok  f32 N=%d\n", n);
+    return 0;
+}
+
+int main()
+{
+    int bad = 0;
+    bad |= scenario(64, 64, 16, 2, 9, 16);
+    bad |= scenario(64, 40, 24, 1, 7, 50);      // padded frame, hop not a divisor
+    bad |= scenario(1024, 1024, 256, 2, 11, 256);  // fast kernels, register overlap-add
+    bad |= scenario(1024, 1000, 250, 1, 6, 100);   // fast kernels, scalar loads
+    bad |= scenario(100, 81, 20, 2, 8, 20);        // chirp-z
+    bad |= scenario(7, 7, 2, 1, 12, 3);
+    bad |= scenario_f32(64, 16, 2, 9);
+    bad |= scenario_f32(1024, 256, 1, 7);
+    std::printf(bad ? "FAILURES\n" : "all scenarios ran\n");
+    return bad;
+}
