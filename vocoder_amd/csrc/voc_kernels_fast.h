@@ -377,18 +377,19 @@ VOC_UNROLL(VOC_POLAR_UNROLL)
             php[pe] = pha;
             php[q] = phb;
         }
-        if (tid == 0) {  // DC and Nyquist bins are real: phase 0 or pi, magnitude |x|
+        // DC and Nyquist bins are real: phase 0 or pi, magnitude |x|.  Two different waves take one
+        // each, so that no wave (and no SIMD) carries both on top of its four bin pairs.
+        if (tid == 0 || tid == T / 2) {
             const C2 z0 = lds[lds_pad(0)];
-            const R x0 = z0.x + z0.y, xm = z0.x - z0.y;
-            const R ph0 = x0 < (R)0 ? (R)kPi : (R)0, phm = xm < (R)0 ? (R)kPi : (R)0;
+            const bool dc = tid == 0;
+            const R xr = dc ? z0.x + z0.y : z0.x - z0.y;
+            const int kb = dc ? 0 : M;
+            const R phr = xr < (R)0 ? (R)kPi : (R)0;
             if (emit) {
-                mrow[0] = fabs(x0) * a.vol;
-                mrow[M] = fabs(xm) * a.vol;
-                irow[0] = phase_inc(p, 0, ph0 - php[0]);
-                irow[M] = phase_inc(p, M, phm - php[M]);
+                mrow[kb] = fabs(xr) * a.vol;
+                irow[kb] = phase_inc(p, kb, phr - php[kb]);
             }
-            php[0] = ph0;
-            php[M] = phm;
+            php[kb] = phr;
         }
         // slide the sample window by one hop
 #pragma unroll
