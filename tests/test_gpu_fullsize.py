@@ -84,3 +84,36 @@ def test_cpu_reference_config_full_size(gpu_lib, orc):
     assert Hh.rel_l2(y, r["y"]) <= Hh.TOL_L2
     assert np.array_equal(left, r["leftover"])
     par.close()
+
+
+def test_filtered_configs_full_size(gpu_lib, orc):
+    """The filtered benchmark configurations at their full shapes, sampled streams against the oracle
+    pipeline: `--pitchShiftInterpolate 2 --lowpassBrickwall 1000` on 1024 channels (N = 4096), and
+    `--playSpeed 2` on 512 channels (N = 8192; randomPhase is left out here, its values are defined by
+    the library's own generator and checked in test_gpu_filters.py)."""
+    import torch
+    from fractions import Fraction
+    from vocoder_amd import vocoder as V, conduit as Cd, filter as Fl
+    dev = torch.device("cuda:0")
+    length = 2_880_000
+    cases = [
+        (4096, 1024, 1024, Fl.pitch_shift_interpolate(2.0) >> Fl.lowpass_brickwall(1000.0),
+         [("pitch_shift", 2.0), ("lowpass_brickwall", 1000.0)], None),
+        (8192, 2048, 512, Fl.play_speed(Fraction(2)), [], Fraction(2)),
+    ]
+    for n, h, c, filt, chain, speed in cases:
+        win = 0.5 * (1 - np.cos(2 * np.pi * np.arange(n) / n))
+        par = V.VocoderParams(n, h, win, lib=gpu_lib)
+        x = _streams(torch, c, length, dev)
+        y, aph, sph = Cd.process_filter_dev(par, filt.bind(par, 48000.0 / n), x)
+        torch.cuda.synchronize()
+        f_in = Cd.num_frames(par, length)
+        f_out = f_in if speed is None else int(f_in * speed)
+        assert y.shape == (c, Cd.ola_length(par, f_out, h))
+        assert torch.isfinite(y).all()
+        for s in (0, c - 1):
+            ref = Hh.oracle_filtered(orc, n, h, win, x[s].cpu().numpy(), 48000.0 / n, chain, speed)
+            assert Hh.rel_l2(y[s].cpu().numpy(), ref["y"]) <= Hh.TOL_L2
+        del x, y
+        par.close()
+        torch.cuda.empty_cache()
