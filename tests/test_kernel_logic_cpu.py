@@ -64,3 +64,22 @@ def test_steps_and_framing(emu_lib, orc):
             assert np.array_equal(y[ch], orc.sum_frames_e(chunk, h, list(frames[ch])).ravel())
     assert par.lib.dll.voc_volume_coeff(par.handle) == orc.volume_coeff(h, win)
     par.close()
+
+
+@pytest.mark.parametrize("slots,c", [(2, 5), (2, 4), (3, 4), (4, 5)])
+def test_uncut_leading_channels_equal_fully_tiled_result(emu_lib, orc, slots, c, monkeypatch):
+    """With more channels than workgroup slots, whole rounds of channels run as one synthesis tile each
+    and only the last partial round is cut (and carried): same bits as the all-cut schedule."""
+    from vocoder_amd import vocoder as V, conduit as Cd
+    n, h = 1024, 256
+    win = 0.5 * (1 - np.cos(2 * np.pi * np.arange(n) / n))
+    rng = np.random.default_rng(slots * 10 + c)
+    x = rng.standard_normal((c, n + h * 70 + 9))
+    ph = (rng.uniform(-3, 3, (c, n // 2 + 1)), rng.uniform(-3, 3, (c, n // 2 + 1)))
+    monkeypatch.setenv("VOC_SYN_TILE_LEN", "0")
+    monkeypatch.delenv("VOC_SYN_SLOTS", raising=False)
+    ref = Cd.process_with(V.VocoderParams(n, h, win, lib=emu_lib), x, phases=ph)
+    monkeypatch.setenv("VOC_SYN_SLOTS", str(slots))
+    got = Cd.process_with(V.VocoderParams(n, h, win, lib=emu_lib), x, phases=ph)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    assert np.array_equal(got[2][0], ref[2][0]) and np.array_equal(got[2][1], ref[2][1])

@@ -690,6 +690,7 @@ struct SynArgsT {
     long long out_len;        // OLA: samples per channel, last chunk zero padded
     long long F;
     int tile_len, tiles, halo;
+    long long unsplit;        // the first `unsplit` channels run as one tile each (no carry); the others in `tiles` tiles
 };
 using SynArgs = SynArgsT<double>;
 
@@ -701,10 +702,12 @@ __global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) synthesis_kernel(ParamsT<R> 
     VOC_SMEM(C2, lds);
     R *ring = reinterpret_cast<R *>(lds + Cfg<LOG2M>::LDS_CPLX);  // OLA partial sums, W values
     const int tid = threadIdx.x;
-    const long long c = blockIdx.x / a.tiles;
-    const int tile = blockIdx.x % a.tiles;
+    const bool whole = (long long)blockIdx.x < a.unsplit;  // leading channels: one tile over all frames
+    const long long rest = (long long)blockIdx.x - a.unsplit;
+    const long long c = whole ? (long long)blockIdx.x : a.unsplit + rest / a.tiles;
+    const int tile = whole ? 0 : (int)(rest % a.tiles);
     const long long f0 = (long long)tile * a.tile_len;
-    const long long f1 = (f0 + a.tile_len < a.F) ? f0 + a.tile_len : a.F;
+    const long long f1 = (whole || f0 + a.tile_len >= a.F) ? a.F : f0 + a.tile_len;
     const bool own_half = (tid == T - 1);
     // OLA: frames that reach into this tile's first output sample are recomputed, in order,
     // so that every output sample is summed oldest frame first with no cross-tile exchange.
@@ -713,7 +716,7 @@ __global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) synthesis_kernel(ParamsT<R> 
 
     R ph[2 * NP + 1];
     if (IN_MODE == SYN_IN_POLAR) {
-        const R *pi = (tile == 0) ? a.phase_in + c * p.K : a.carry + (c * a.tiles + tile) * p.K;
+        const R *pi = (tile == 0) ? a.phase_in + c * p.K : a.carry + ((c - a.unsplit) * a.tiles + tile) * p.K;
 #pragma unroll
         for (int m = 0; m < NP; ++m) {
             const int pr = tid + m * T;

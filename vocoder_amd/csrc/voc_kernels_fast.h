@@ -423,15 +423,17 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
     R *php = reinterpret_cast<R *>(lds + FastCfg<LOG2M>::LDS_CPLX);  // accumulated phase, K bins
     const R *ldsd = reinterpret_cast<const R *>(lds);
     const int tid = threadIdx.x;
-    const long long c = blockIdx.x / a.tiles;
-    const int tile = blockIdx.x % a.tiles;
+    const bool whole = (long long)blockIdx.x < a.unsplit;  // leading channels: one tile over all frames
+    const long long rest = (long long)blockIdx.x - a.unsplit;
+    const long long c = whole ? (long long)blockIdx.x : a.unsplit + rest / a.tiles;
+    const int tile = whole ? 0 : (int)(rest % a.tiles);
     const long long f0 = (long long)tile * a.tile_len;
-    const long long f1 = (f0 + a.tile_len < a.F) ? f0 + a.tile_len : a.F;
+    const long long f1 = (whole || f0 + a.tile_len >= a.F) ? a.F : f0 + a.tile_len;
     const long long halo = OLA ? ((long long)a.halo < f0 ? (long long)a.halo : f0) : 0;
     const long long fs = f0 - halo;
 
     {
-        const R *pi = (tile == 0) ? a.phase_in + c * p.K : a.carry + (c * a.tiles + tile) * p.K;
+        const R *pi = (tile == 0) ? a.phase_in + c * p.K : a.carry + ((c - a.unsplit) * a.tiles + tile) * p.K;
         for (int k = tid; k < p.K; k += T) php[k] = pi[k];
     }
     __syncthreads();

@@ -43,7 +43,7 @@ struct voc_ctx {
     voc::ParamsT<float> params_f{};
     void *ws = nullptr;
     size_t ws_bytes = 0;
-    int ana_tile_override = 0, syn_tile_override = 0;
+    int ana_tile_override = 0, syn_tile_override = 0, syn_slots_override = 0;
     bool force_generic = false;  // VOC_FORCE_GENERIC=1: never take the specialised kernels
 #ifndef VOC_EMU
     bool profiling = false;
@@ -188,7 +188,7 @@ void launch_analysis(voc_ctx *c, const voc::AnaArgsT<R> &a, long long channels, 
 template <int IN_MODE, int OUT_MODE, class R = double>
 void launch_synthesis(voc_ctx *c, const voc::SynArgsT<R> &a, long long channels, hipStream_t st)
 {
-    const long long grid = channels * a.tiles;
+    const long long grid = a.unsplit + (channels - a.unsplit) * a.tiles;
     if (grid <= 0) return;
     if (grid > 0x7fffffffLL) throw HipFail{hipErrorInvalidValue, "synthesis grid too large"};
     LaunchTimer timer(c, IN_MODE == voc::SYN_IN_SPEC ? KIND_OTHER : KIND_SYNTHESIS, st);
@@ -295,7 +295,7 @@ bool launch_synthesis_fast(voc_ctx *c, const voc::SynArgsT<R> &a, long long chan
     if (!fast_sizes(c)) return false;
     const int nh = ola ? fast_ola_nhp(c, a) : 8;
     if (ola && nh == 0) return false;
-    const long long grid = channels * a.tiles;
+    const long long grid = a.unsplit + (channels - a.unsplit) * a.tiles;
     if (grid <= 0) return true;
     if (grid > 0x7fffffffLL) throw HipFail{hipErrorInvalidValue, "synthesis grid too large"};
     LaunchTimer timer(c, KIND_SYNTHESIS, st);
@@ -536,9 +536,54 @@ void phase_advance_dev(voc_ctx *c, const double *inc, long long ldk, long long F
     HIPCHK(hipGetLastError());
 }
 
+// Workgroups of the specialised synthesis kernel the chip holds at once (0: the generic kernel runs).
+long long synthesis_slots(const voc_ctx *c)
+{
+    if (!fast_sizes(c)) return 0;
+    if (c->syn_slots_override > 0) return c->syn_slots_override;  // VOC_SYN_SLOTS: lets small tests reach this path
+    const bool f32 = c->precision == VOC_PRECISION_F32;
+    const long long t = c->M / 8;
+    const long long lds = (long long)((c->M + (c->M >> 3) + 2) * 2 + ((c->K + 1) & ~1)) * (f32 ? 4 : 8);
+    long long by_lds = (long long)kLdsLimit / lds, by_regs = (f32 ? 16 : 12) * 64 / t;
+    long long per_cu = by_lds < by_regs ? by_lds : by_regs;
+    if (per_cu < 1) per_cu = 1;
+    return 256 * per_cu;
+}
+
+// With more channels than the chip holds workgroups, whole rounds of channels need no cut at all:
+// they run as one tile each, first, and only the channels of the last, partial round are cut into
+// tiles (and need the carry pass).  Returns the number of uncut leading channels and, for the
+// others, the tiling.
+long long synthesis_unsplit(const voc_ctx *c, long long channels, long long F, int halo, bool fused, int *tile_len, int *tiles)
+{
+    const long long slots = synthesis_slots(c);
+    if (c->syn_tile_override > 0 || slots == 0 || !fused || channels <= slots) return 0;
+    const long long unsplit = channels / slots * slots, rest = channels - unsplit;
+    if (rest == 0) {
+        *tile_len = (int)F;
+        *tiles = 1;
+        return channels;
+    }
+    long long min_tile = 8LL * (halo + 1);
+    if (min_tile < 16) min_tile = 16;
+    long long t = slots / rest, max_tiles = F / min_tile;
+    if (t > max_tiles) t = max_tiles;
+    if (t <= 1) {
+        *tile_len = (int)F;
+        *tiles = 1;
+        return channels;
+    }
+    long long tl = (F + t - 1) / t;
+    if (tl <= halo) tl = halo + 1;
+    *tile_len = (int)tl;
+    *tiles = (int)((F + tl - 1) / tl);
+    return unsplit;
+}
+
 struct RtPlan {
     long long F, out_len, ldk;
     int ana_tile, ana_tiles, syn_tile, syn_tiles, halo;
+    long long syn_unsplit;     // leading channels that run as one synthesis tile each
     bool fused_ola;            // overlap-add ring fits in LDS beside the FFT buffer
     size_t per_channel_bytes;  // STFT + carry + two phase snapshots (+ frames when not fused)
 };
@@ -556,6 +601,7 @@ RtPlan roundtrip_plan(const voc_ctx *c, long long len, long long group, long lon
         r.ana_tile = analysis_tile_len(c, group, r.F);
         r.ana_tiles = (int)((r.F + r.ana_tile - 1) / r.ana_tile);
         synthesis_tiling(c, group, r.F, r.halo, &r.syn_tile, &r.syn_tiles);
+        r.syn_unsplit = synthesis_unsplit(c, group, r.F, r.halo, r.fused_ola, &r.syn_tile, &r.syn_tiles);
     }
     r.per_channel_bytes = (size_t)(2 * r.F * r.ldk + (long long)(r.syn_tiles > 1 ? r.syn_tiles : 0) * c->K + 2LL * c->K +
                                    (r.fused_ola ? 0 : r.F * c->W)) *
@@ -625,11 +671,14 @@ void roundtrip_dev(voc_ctx *c, const R *x, long long x_stride, long long len, lo
         bool done = launch_analysis_fast<R>(c, a, G, st);
         if (!done) launch_analysis<false, false, R>(c, a, G, st);
 
-        if (r.syn_tiles > 1) {
-            const long long chains = G * c->K;
+        // (a group smaller than the planned one keeps the plan's tiling; only its uncut part shrinks)
+        const long long unsplit = r.syn_unsplit < G ? r.syn_unsplit : (r.syn_tiles > 1 ? 0 : G);
+        if (r.syn_tiles > 1 && G > unsplit) {
+            const long long chains = (G - unsplit) * c->K;
             LaunchTimer timer(c, KIND_CARRY, st);
             hipLaunchKernelGGL(voc::phase_carry_kernel<R>, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st,
-                               params_of<R>(c), (const R *)inc, r.ldk, F, (const R *)pinS, carry, r.syn_tile, r.syn_tiles, r.halo, G);
+                               params_of<R>(c), (const R *)(inc + (size_t)unsplit * F * r.ldk), r.ldk, F,
+                               (const R *)(pinS + unsplit * c->K), carry, r.syn_tile, r.syn_tiles, r.halo, G - unsplit);
             HIPCHK(hipGetLastError());
         }
         voc::SynArgsT<R> s{};
@@ -645,6 +694,7 @@ void roundtrip_dev(voc_ctx *c, const R *x, long long x_stride, long long len, lo
         s.F = F;
         s.tile_len = r.syn_tile;
         s.tiles = r.syn_tiles;
+        s.unsplit = unsplit;
         s.halo = r.halo;
         if (r.fused_ola) {
             done = launch_synthesis_fast<R>(c, s, G, true, st);
@@ -726,6 +776,7 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
         c->vol = (double)H / s;
         c->ana_tile_override = env_int("VOC_ANA_TILE_LEN");
         c->syn_tile_override = env_int("VOC_SYN_TILE_LEN");
+        c->syn_slots_override = env_int("VOC_SYN_SLOTS");
         c->force_generic = env_int("VOC_FORCE_GENERIC") != 0;
 
         // per-pass Stockham twiddles, laid out as voc::fft_passes reads them: the pass at stride NS
