@@ -83,3 +83,16 @@ def test_uncut_leading_channels_equal_fully_tiled_result(emu_lib, orc, slots, c,
     got = Cd.process_with(V.VocoderParams(n, h, win, lib=emu_lib), x, phases=ph)
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
     assert np.array_equal(got[2][0], ref[2][0]) and np.array_equal(got[2][1], ref[2][1])
+
+
+def test_uncut_leading_channels_in_the_signal_level_entry(emu_lib, monkeypatch):
+    import torch
+    from vocoder_amd import vocoder as V, conduit as Cd
+    n, h, c = 1024, 256, 5
+    win = 0.5 * (1 - np.cos(2 * np.pi * np.arange(n) / n))
+    x = np.random.default_rng(77).standard_normal((c, n + h * 70 + 9))
+    monkeypatch.delenv("VOC_SYN_SLOTS", raising=False)
+    ref = Cd.process_with(V.VocoderParams(n, h, win, lib=emu_lib), x)
+    monkeypatch.setenv("VOC_SYN_SLOTS", "2")
+    y, aph, sph = Cd.process_filter_dev(V.VocoderParams(n, h, win, lib=emu_lib), None, torch.from_numpy(x))
+    assert np.array_equal(y.numpy(), ref[0]) and np.array_equal(sph.numpy(), ref[2][1])

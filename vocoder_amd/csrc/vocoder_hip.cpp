@@ -476,6 +476,8 @@ void analysis_signal_dev(voc_ctx *c, const double *x, long long x_stride, long l
 constexpr size_t kLdsLimit = 160 * 1024;
 
 // synthesisStage + sumFramesE: y rows receive y_len samples each (zeros past the last frame).
+long long synthesis_unsplit(const voc_ctx *c, long long channels, long long F, int halo, bool fused, int *tile_len, int *tiles);
+
 void synthesis_signal_dev(voc_ctx *c, const double *mag, const double *inc, long long ldk, long long F, long long C,
                           double *phase_io, double *y, long long y_stride, long long y_len, hipStream_t st)
 {
@@ -484,6 +486,7 @@ void synthesis_signal_dev(voc_ctx *c, const double *mag, const double *inc, long
     const int halo = fused ? (c->W + c->H - 1) / c->H - 1 : 0;
     int tile_len, tiles;
     synthesis_tiling(c, C, F, halo, &tile_len, &tiles);
+    const long long unsplit = synthesis_unsplit(c, C, F, halo, fused, &tile_len, &tiles);
     const size_t nph = (size_t)C * c->K;
     const size_t ncarry = tiles > 1 ? (size_t)C * tiles * c->K : 0;
     const size_t nframes = fused ? 0 : (size_t)C * F * c->W;
@@ -492,11 +495,12 @@ void synthesis_signal_dev(voc_ctx *c, const double *mag, const double *inc, long
     double *carry = pin + nph;
     double *frames = carry + ncarry;
     HIPCHK(hipMemcpyAsync(pin, phase_io, nph * sizeof(double), hipMemcpyDeviceToDevice, st));
-    if (tiles > 1) {
-        const long long chains = C * c->K;
+    if (tiles > 1 && C > unsplit) {
+        const long long chains = (C - unsplit) * c->K;
         LaunchTimer timer(c, KIND_CARRY, st);
         hipLaunchKernelGGL(voc::phase_carry_kernel<double>, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, c->params,
-                           inc, ldk, F, pin, carry, tile_len, tiles, halo, C);
+                           inc + (size_t)unsplit * F * ldk, ldk, F, (const double *)(pin + unsplit * c->K), carry, tile_len, tiles,
+                           halo, C - unsplit);
         HIPCHK(hipGetLastError());
     }
     voc::SynArgs s{};
@@ -513,6 +517,7 @@ void synthesis_signal_dev(voc_ctx *c, const double *mag, const double *inc, long
     s.tile_len = tile_len;
     s.tiles = tiles;
     s.halo = halo;
+    s.unsplit = unsplit;
     if (fused) {
         if (!launch_synthesis_fast(c, s, C, true, st)) launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_OLA>(c, s, C, st);
     } else {
