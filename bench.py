@@ -34,7 +34,7 @@ BYTES_SYNTHESIS = 16 * K_BINS + 8 * HOP            # (mag, ph_inc) in, unique ou
 BYTES_FRAME = BYTES_ANALYSIS + BYTES_SYNTHESIS     # 81 952 B: the algorithmic bytes of one frame
 
 
-def make_streams(c, length, dev, rank):
+def make_streams(c, length, dev, rank, dtype=None):
     """x_s[n] = 0.5 sin(2 pi f_s n / 48000 + theta_s) + 1e-2 u_s[n], f_s = 110 * 2^((s mod 72)/12) Hz."""
     g = torch.Generator(device=dev)
     g.manual_seed(0x5EED + rank)
@@ -42,7 +42,7 @@ def make_streams(c, length, dev, rank):
     s = torch.arange(c, device=dev) + rank * c
     f = 110.0 * torch.pow(2.0, (s % 72).double() / 12.0)
     theta = torch.rand(c, generator=g, dtype=torch.float64, device=dev) * (2 * np.pi)
-    x = torch.empty(c, length, dtype=torch.float64, device=dev)
+    x = torch.empty(c, length, dtype=dtype or torch.float64, device=dev)
     for lo in range(0, c, 32):
         hi = min(c, lo + 32)
         x[lo:hi] = 0.5 * torch.sin((2 * np.pi / RATE) * f[lo:hi, None] * n[None, :] + theta[lo:hi, None])
@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=1024, help="streams per GPU (metric configuration: 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=("f64", "f32"), default="f64",
+                    help="f32: the single-precision variant (not the metric; reported with dtype f32)")
     ap.add_argument("--cpu-streams", type=int, default=24, help="streams of the workload the CPU oracle is timed on")
     args = ap.parse_args()
 
@@ -84,13 +86,15 @@ def main():
 
     from vocoder_amd import vocoder as V, conduit as Cd, window as Wn
     win = Wn.hann_window(N_FFT)
-    par = V.VocoderParams(N_FFT, HOP, win, device=local_rank)
+    f32 = args.precision == "f32"
+    tdt = torch.float32 if f32 else torch.float64
+    par = V.VocoderParams(N_FFT, HOP, win, device=local_rank, precision=args.precision)
     c, length = args.streams, RATE * SECONDS
     frames_per_stream = Cd.num_frames(par, length)
     frames = c * frames_per_stream
-    x = make_streams(c, length, dev, rank)
-    y = torch.empty(c, Cd.ola_length(par, frames_per_stream, HOP), dtype=torch.float64, device=dev)
-    aph = torch.zeros(c, par.K, dtype=torch.float64, device=dev)
+    x = make_streams(c, length, dev, rank, tdt)
+    y = torch.empty(c, Cd.ola_length(par, frames_per_stream, HOP), dtype=tdt, device=dev)
+    aph = torch.zeros(c, par.K, dtype=tdt, device=dev)
     sph = torch.zeros_like(aph)
     ws = torch.empty(Cd.roundtrip_workspace_bytes(par, length, c), dtype=torch.uint8, device=dev)
 
@@ -123,17 +127,19 @@ def main():
         avg = [ms[0][i] / ms[1][i] if ms[1][i] else 0.0 for i in range(3)]     # ms per launch
         dom = 0 if avg[0] >= avg[2] else 2
         # bytes one launch moves: the library may cut a step's frames into several launches of a kernel
-        alg = (BYTES_ANALYSIS, 0, BYTES_SYNTHESIS)[dom] * frames * args.steps / max(int(ms[1][dom]), 1)
+        scale = 0.5 if f32 else 1.0                                            # float buffers: half the bytes
+        alg = scale * (BYTES_ANALYSIS, 0, BYTES_SYNTHESIS)[dom] * frames * args.steps / max(int(ms[1][dom]), 1)
         achieved = alg / (avg[dom] * 1e-3) / 1e9 if avg[dom] else 0.0
         out = {
-            "metric": "STFT frames/sec analysis+synthesis (N=4096,hop=1024,fp64); % HBM roofline",
+            "metric": "STFT frames/sec analysis+synthesis (N=4096,hop=1024,fp64); % HBM roofline" if not f32 else
+                      "STFT frames/sec analysis+synthesis (N=4096,hop=1024), single-precision variant; % HBM roofline",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "1024 mono synthetic streams x 60 s @48 kHz per GPU, N=W=4096 hop=1024 fp64 "
-                                   "identity round-trip (Hann), configs[1]",
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"{c} mono synthetic streams x 60 s @48 kHz per GPU, N=W=4096 hop=1024 "
+                                   f"{'fp32' if f32 else 'fp64'} identity round-trip (Hann), configs[1]",
                        "streams_per_gpu": c, "frames_per_step_per_gpu": frames, "sharding": "by stream, no collective"},
-            "hbm_roofline_frac_whole_path": value / world * BYTES_FRAME / HBM_PEAK,
+            "hbm_roofline_frac_whole_path": value / world * scale * BYTES_FRAME / HBM_PEAK,
             "kernel_ms": {names[i]: avg[i] for i in range(3) if ms[1][i]},
             "kernel_launches_per_step": {names[i]: int(ms[1][i]) // args.steps for i in range(3) if ms[1][i]},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK / 1e9,
@@ -143,13 +149,13 @@ def main():
         if os.path.exists(tfile):
             try:
                 t = json.load(open(tfile))
-                if t.get("streams_per_gpu") == args.streams:   # measured on this workload only
+                if t.get("streams_per_gpu") == args.streams and not f32:   # measured on this workload only
                     out["roofline"]["traffic"] = t.get(names[dom])
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:
             ncpu = min(args.cpu_streams, c)
-            v, nfr, secs = cpu_baseline(win, x[:ncpu].cpu().numpy())
+            v, nfr, secs = cpu_baseline(win, x[:ncpu].double().cpu().numpy())
             out["cpu_baseline"] = {"value": v, "unit": "frames/s", "cores": 1, "kind": "port",
                                    "sample": f"{ncpu} of the {c} streams x 60 s ({nfr} frames, {secs:.1f} s of CPU time), "
                                              "C restatement of the reference path"}
