@@ -562,7 +562,14 @@ long long synthesis_slots(const voc_ctx *c)
 long long synthesis_unsplit(const voc_ctx *c, long long channels, long long F, int halo, bool fused, int *tile_len, int *tiles)
 {
     const long long slots = synthesis_slots(c);
-    if (c->syn_tile_override > 0 || slots == 0 || !fused || channels <= slots) return 0;
+    if (c->syn_tile_override > 0 || slots == 0 || !fused) return 0;
+    if (channels < slots) {
+        // one nearly full round: cutting would buy little and cost the carry pass
+        if (channels * 20 < slots * 17) return 0;
+        *tile_len = (int)F;
+        *tiles = 1;
+        return channels;
+    }
     const long long unsplit = channels / slots * slots, rest = channels - unsplit;
     if (rest == 0) {
         *tile_len = (int)F;
