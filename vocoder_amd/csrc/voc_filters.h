@@ -29,6 +29,9 @@ struct FilterOp {
 
 struct FilterProg {
     int n;
+    // what the chain as a whole needs from / changes in memory (filled in by the host): a gain-only
+    // chain never touches ph_inc, a random-phase chain never touches the moduli and never reads ph_inc
+    int load_mag, store_mag, load_inc, store_inc;
     FilterOp op[kMaxFilterOps];
 };
 
@@ -123,8 +126,8 @@ __global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p
             m[j] = 0.0;
             ic[j] = 0.0;
             if (k < K) {
-                m[j] = mrow[k];
-                ic[j] = irow[k];
+                if (prog.load_mag) m[j] = mrow[k];
+                if (prog.load_inc) ic[j] = irow[k];
             }
         }
         for (int o = 0; o < prog.n; ++o) {
@@ -203,8 +206,8 @@ __global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p
         for (int j = 0; j < NE; ++j) {
             const int k = tid + T * j;
             if (k < K) {
-                mrow[k] = m[j];
-                irow[k] = ic[j];
+                if (prog.store_mag) mrow[k] = m[j];
+                if (prog.store_inc) irow[k] = ic[j];
             }
         }
     }
