@@ -205,6 +205,10 @@ def test_device_entry_matches_host_entry_and_runs_the_native_library(gpu_lib, or
     Cd.process_dev(par, xd, yd2, ad, sd, workspace=small)
     torch.cuda.synchronize()
     assert np.array_equal(yd2[:, :-4].cpu().numpy(), y_host)
+    tiny = torch.empty(64, dtype=torch.uint8, device=dev)       # less than one channel needs: refused, nothing run
+    with pytest.raises(V.VocoderError) as e:
+        Cd.process_dev(par, xd, yd2, ad, sd, workspace=tiny)
+    assert e.value.status == -5
     # rows that are not 16-byte aligned take the generic overlap-add kernel: same result to rounding
     yd3 = torch.full((c, Cd.ola_length(par, f, h) + 3), 7.0, dtype=torch.float64, device=dev)
     ad.zero_(); sd.zero_()

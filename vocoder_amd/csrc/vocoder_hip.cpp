@@ -636,7 +636,6 @@ void roundtrip_dev(voc_ctx *c, const R *x, long long x_stride, long long len, lo
     if (F <= 0) return;
 
     // channels per pass: as many as the workspace holds
-    RtPlan full = roundtrip_plan(c, len, C, chunk);
     long long group = C;
     if (!ws) {
         size_t cap = (size_t)160 << 30;
@@ -650,9 +649,8 @@ void roundtrip_dev(voc_ctx *c, const R *x, long long x_stride, long long len, lo
         while (group > 1 && roundtrip_plan(c, len, group, chunk).per_channel_bytes * (size_t)group > (size_t)ws_bytes)
             group = (group + 1) / 2;
         if (roundtrip_plan(c, len, group, chunk).per_channel_bytes * (size_t)group > (size_t)ws_bytes)
-            throw HipFail{hipErrorInvalidValue, "workspace smaller than one channel needs"};
+            throw StatusFail{VOC_ERR_SIZE};  // workspace smaller than one channel needs
     }
-    (void)full;
 
     for (long long c0 = 0; c0 < C; c0 += group) {
         const long long G = (C - c0 < group) ? C - c0 : group;
