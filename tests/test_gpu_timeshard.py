@@ -113,3 +113,38 @@ def test_time_sharded_matches_sequential(gpu_lib, orc, n, hop, world, frames_per
     ref = orc.roundtrip(n, hop, win, x[0], hop, np.zeros(par.K), np.zeros(par.K))
     yy = y[0].cpu().numpy()
     assert np.linalg.norm(yy - ref["y"]) / np.linalg.norm(ref["y"]) <= TOL_L2
+
+
+@pytest.mark.parametrize("chain", ["identity", "envelope", "pitch+lowpass"])
+def test_one_rank_in_pieces_equals_whole_signal(gpu_lib, orc, chain):
+    """A long signal walked in runs of frames: phases carried run to run reproduce the unpieced
+    run's phases bit for bit; samples differ only at run boundaries, by the re-associated overlap-add."""
+    import torch
+    from vocoder_amd import vocoder as V, conduit as Cd, timeshard as T, filter as Fl
+    n, hop = 4096, 1024
+    win = _hann(n)
+    par = V.VocoderParams(n, hop, win, lib=gpu_lib)
+    c, frames = 5, 75
+    length = n + hop * (frames - 1) + 17
+    x = _signal(c, length)
+    xt = torch.from_numpy(x).cuda()
+    descr = {"identity": None, "envelope": Fl.envelope_filter(32),
+             "pitch+lowpass": Fl.pitch_shift_interpolate(2.0) >> Fl.lowpass_brickwall(1000.0)}[chain]
+    filt = descr.bind(par, 48000.0 / n) if descr is not None else None
+    reads = []
+
+    def source(lo, hi):
+        reads.append(hi - lo)
+        return xt[:, lo:hi].contiguous()
+
+    y, (aph, sph) = T.process_pieces(par, source, length, 16, filt=filt)
+    y_seq, aph_seq, sph_seq = Cd.process_filter_dev(par, filt, xt)
+    torch.cuda.synchronize()
+    assert len(reads) == 5 and max(reads) <= 15 * hop + n           # 75 frames in 5 runs of 15, one walk on one rank
+    assert y.shape == y_seq.shape
+    rel = (torch.linalg.norm(y - y_seq) / torch.linalg.norm(y_seq)).item()
+    assert rel <= 1e-14, rel
+    assert torch.equal(aph, aph_seq) and torch.equal(sph, sph_seq)
+    if chain == "identity":
+        ref = orc.roundtrip(n, hop, win, x[1], hop, np.zeros(par.K), np.zeros(par.K))
+        assert np.linalg.norm(y[1].cpu().numpy() - ref["y"]) / np.linalg.norm(ref["y"]) <= TOL_L2

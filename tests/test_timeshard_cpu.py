@@ -119,3 +119,128 @@ def test_two_gloo_ranks_shard_time(emu_lib, orc, tmp_path):
             assert _wrap_err(p["aph"][ch], ref["ana_phase"]) <= 1e-9
             assert _wrap_err(p["sph"][ch], ref["syn_phase"]) <= 1e-9
     assert np.array_equal(parts[0]["sph"], parts[1]["sph"]) and np.array_equal(parts[0]["aph"], parts[1]["aph"])
+
+
+def _bound(par, chain, step):
+    from vocoder_amd import filter as Fl
+    f = Fl.id_filter()
+    for name, *prm in chain:
+        fn = {"pitch_shift": Fl.pitch_shift_interpolate, "envelope": Fl.envelope_filter}.get(name) or getattr(Fl, name)
+        f = Fl.compose_filters(f, fn(*prm))
+    return f.bind(par, step)
+
+
+PIECE_CHAINS = [[], [("pitch_shift", 1.5), ("lowpass_brickwall", 9000.0)], [("envelope", 5)]]
+
+
+def test_pieces_cover_a_segment(emu_lib):
+    from vocoder_amd import vocoder as V, timeshard as T
+    par = V.VocoderParams(64, 16, _hann(64), lib=emu_lib)
+    sp = T.plan(par, 64 + 16 * 40, 2, 1)
+    for want in (1, 3, 4, 7, 1000):
+        runs = T.pieces_of(par, sp, want)
+        assert runs[0][0] == sp.f_lo and runs[-1][1] == sp.f_hi
+        assert all(a[1] == b[0] for a, b in zip(runs, runs[1:]))
+        assert all((hi - lo) * 16 >= 48 or len(runs) == 1 for lo, hi in runs)     # a run holds its predecessor's overlap
+    assert len(T.pieces_of(par, sp, 1)) == sp.frames // 3                          # runs of one frame are too short: 3 each
+
+
+@pytest.mark.parametrize("chain", PIECE_CHAINS, ids=lambda c: "+".join(s[0] for s in c) or "identity")
+@pytest.mark.parametrize("n,w,hop,piece", [(64, 64, 16, 5), (64, 48, 16, 4), (32, 32, 32, 1), (64, 24, 32, 2)])
+def test_one_rank_in_pieces_matches_oracle(emu_lib, orc, n, w, hop, piece, chain):
+    """A single rank walking its signal in runs of a few frames: analysis and synthesis phases are
+    carried exactly; only the overlap-add across a run boundary is re-associated."""
+    import torch
+    from helpers import oracle_filtered
+    from vocoder_amd import vocoder as V, timeshard as T
+    win = _hann(w)
+    par = V.VocoderParams(n, hop, win, lib=emu_lib)
+    c, length = 2, w + hop * 23 + 3
+    x = _signal(c, length)
+    xt = torch.from_numpy(x)
+    step = 48000.0 / n
+    filt = _bound(par, chain, step) if chain else None
+    got = []
+    y, (aph, sph) = T.process_pieces(par, lambda lo, hi: xt[:, lo:hi].contiguous(), length, piece, filt=filt)
+    _, (aph2, sph2) = T.process_pieces(par, lambda lo, hi: xt[:, lo:hi].contiguous(), length, piece, filt=filt,
+                                       sink=lambda lo, t: got.append((lo, t.clone())))
+    pos = 0
+    for lo, t in got:                                   # one rank: runs arrive in order, nothing is held back
+        assert lo == pos
+        pos += t.shape[1]
+    assert torch.equal(torch.cat([t for _, t in got], dim=1), y) and torch.equal(sph, sph2)
+    for ch in range(c):
+        ref = oracle_filtered(orc, n, hop, win, x[ch], step, chain)
+        assert y.shape[1] == ref["y"].size
+        assert np.linalg.norm(y[ch].numpy() - ref["y"]) / np.linalg.norm(ref["y"]) <= TOL_L2
+        assert _wrap_err(aph[ch].numpy(), ref["ana_phase"]) <= 1e-9
+        assert _wrap_err(sph[ch].numpy(), ref["syn_phase"]) <= 1e-9
+
+
+def test_too_short_for_a_frame_in_pieces(emu_lib):
+    import torch
+    from vocoder_amd import vocoder as V, timeshard as T
+    par = V.VocoderParams(64, 16, _hann(64), lib=emu_lib)
+    xt = torch.zeros((2, 10), dtype=torch.float64)
+    y, (aph, sph) = T.process_pieces(par, lambda lo, hi: xt[:, lo:hi], 10, 4)
+    assert y.shape == (2, 0) and aph.shape == (2, 33) and not sph.any()
+
+
+def _piece_worker(rank, world_size, port, emu_path, out_dir, n, hop, length, chain, piece):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world_size),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    from vocoder_amd import distributed as D, vocoder as V, timeshard as T
+    from vocoder_amd._ffi import Library
+    assert D.init("gloo") == world_size
+    par = V.VocoderParams(n, hop, _hann(n), lib=Library(emu_path))
+    x = torch.from_numpy(_signal(2, length))
+    filt = _bound(par, chain, 48000.0 / n) if chain else None
+    reads, got = [], []
+
+    def source(lo, hi):
+        reads.append((lo, hi))
+        return x[:, lo:hi].contiguous()
+
+    sp = T.plan(par, length, world_size, rank)
+    _, (aph, sph) = T.process_pieces(par, source, length, piece, sink=lambda lo, t: got.append((lo, t.clone())),
+                                     filt=filt)
+    y = torch.zeros((2, sp.out_hi - sp.out_lo), dtype=torch.float64)
+    seen = torch.zeros(sp.out_hi - sp.out_lo, dtype=torch.int64)
+    for lo, t in got:
+        y[:, lo - sp.out_lo:lo - sp.out_lo + t.shape[1]] = t
+        seen[lo - sp.out_lo:lo - sp.out_lo + t.shape[1]] += 1
+    assert bool((seen == 1).all())                      # every owned sample delivered exactly once
+    np.savez(os.path.join(out_dir, f"tp{rank}.npz"), y=y.numpy(), aph=aph.numpy(), sph=sph.numpy(), lo=sp.out_lo,
+             reads=np.array(reads), span=max(hi - lo for lo, hi in reads))
+    D.finish()
+
+
+@pytest.mark.parametrize("chain", PIECE_CHAINS, ids=lambda c: "+".join(s[0] for s in c) or "identity")
+def test_two_gloo_ranks_walk_their_segments_in_pieces(emu_lib, orc, tmp_path, chain):
+    import torch.multiprocessing as mp
+    from helpers import oracle_filtered
+    n, hop, piece = 64, 16, 6
+    length = 64 + 16 * 45 + 7
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_piece_worker, args=(2, port, emu_lib.path, str(tmp_path), n, hop, length, chain, piece), nprocs=2,
+             join=True)
+    parts = [np.load(tmp_path / f"tp{r}.npz") for r in range(2)]
+    y = np.concatenate([p["y"] for p in parts], axis=1)
+    x = _signal(2, length)
+    for p in parts:
+        assert int(p["span"]) <= (piece + 1) * hop + n                 # never more than one run (+ the halo hop) resident
+        walks = 1 if any(s[0] == "envelope" for s in chain) else 2     # zero increments: no pass for the advance
+        assert len(p["reads"]) == walks * 4                            # 23 frames in runs of <= 6: 4 runs per walk
+    for ch in range(2):
+        ref = oracle_filtered(orc, n, hop, _hann(n), x[ch], 48000.0 / n, chain)
+        assert y.shape[1] == ref["y"].size
+        assert np.linalg.norm(y[ch] - ref["y"]) / np.linalg.norm(ref["y"]) <= TOL_L2
+        for p in parts:
+            assert _wrap_err(p["aph"][ch], ref["ana_phase"]) <= 1e-9
+            assert _wrap_err(p["sph"][ch], ref["syn_phase"]) <= 1e-9

@@ -174,8 +174,15 @@ class BoundFilter:
     def __init__(self, par: VocoderParams, freq_step: float, filt: Filter):
         self.par, self.step = par, float(freq_step)
         self.parts = []            # ("chain", _Chain) | ("speed", Fraction)
+        # True when the chain leaves every phase increment at zero: amplitudeFilter0 (Filter.hs:73, under
+        # convolutionFilter and envelopeFilter) zeroes them, gains keep them, interpolating zeros gives zeros
+        self.zero_inc = False
         run = []
         for st in filt.stages:
+            if st[0] in ("convolution", "envelope"):
+                self.zero_inc = True
+            elif st[0] == "random_phase":
+                self.zero_inc = False
             if st[0] == "play_speed":
                 if run:
                     self._add_chains(run)

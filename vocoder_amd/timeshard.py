@@ -29,8 +29,8 @@ from dataclasses import dataclass
 
 from .distributed import shard_range
 
-__all__ = ["SegmentPlan", "plan", "analyse", "local_advance", "start_phase", "synthesise", "add_incoming_tail",
-           "process"]
+__all__ = ["SegmentPlan", "plan", "pieces_of", "analyse", "local_advance", "start_phase", "synthesise",
+           "add_incoming_tail", "process", "process_pieces"]
 
 
 @dataclass(frozen=True)
@@ -64,8 +64,14 @@ def plan(par, length: int, world: int, rank: int, chunk: int | None = None) -> S
         smallest = F // world
         if smallest < 1 or smallest * H < tail:
             raise ValueError(f"{F} frames over {world} ranks: segments shorter than the overlap of {tail} samples")
-    last = rank == world - 1
-    has_prev = rank > 0
+    return _range_plan(par, F, f_lo, f_hi, rank > 0, rank == world - 1, chunk, rank, world)
+
+
+def _range_plan(par, F: int, f_lo: int, f_hi: int, has_prev: bool, last: bool, chunk: int, rank: int = 0,
+                world: int = 1) -> SegmentPlan:
+    """Ranges of the run of frames [f_lo, f_hi) of a signal of F frames.  has_prev: the input
+    starts one hop early; last: the run ends the signal (its output is padded to `chunk`)."""
+    W, H = par.W, par.H
     in_lo = f_lo * H - (H if has_prev else 0)
     in_hi = (f_hi - 1) * H + W
     out_lo = f_lo * H
@@ -78,6 +84,20 @@ def plan(par, length: int, world: int, rank: int, chunk: int | None = None) -> S
         local_len = max((f_hi - f_lo) * H, (f_hi - f_lo - 1) * H + W)
         tail_out = local_len - (out_hi - out_lo)
     return SegmentPlan(rank, world, F, f_lo, f_hi, has_prev, in_lo, in_hi, out_lo, out_hi, local_len, tail_out)
+
+
+def pieces_of(par, sp: SegmentPlan, piece_frames: int):
+    """Cuts the frames of a segment into consecutive runs of about piece_frames frames (equal to
+    within one frame), none shorter than the W - H samples of overlap its successor adds onto."""
+    n = max(1, -(-sp.frames // max(int(piece_frames), 1)))
+    tail = max(par.W - par.H, 0)
+    while n > 1 and (sp.frames // n) * par.H < tail:
+        n -= 1
+    out = []
+    for i in range(n):
+        lo, hi = shard_range(sp.frames, n, i)
+        out.append((sp.f_lo + lo, sp.f_lo + hi))
+    return out
 
 
 def _ptr(t):
@@ -201,3 +221,134 @@ def process(par, x_seg, length: int, chunk: int | None = None, ana_phase=None, s
         dist.broadcast(aph, last, group=group)
         dist.broadcast(sph, last, group=group)
     return y[:, :sp.out_hi - sp.out_lo], (aph, sph)
+
+
+def _zero_increments(filt) -> bool:
+    return bool(filt is not None and getattr(filt, "zero_inc", False))
+
+
+def _filtered(filt, mag, inc):
+    if filt is None:
+        return mag, inc
+    if any(kind == "speed" for kind, _ in filt.parts):
+        raise ValueError("play_speed changes the number of frames: it cannot run on a time-sharded signal")
+    return filt.apply_dev(mag, inc)
+
+
+def process_pieces(par, source, length: int, piece_frames: int, sink=None, filt=None, chunk: int | None = None,
+                   ana_phase=None, syn_phase=None, group=None):
+    """Time-sharded round trip of a signal too long to hold its STFT: every rank walks its segment
+    in runs of about `piece_frames` frames, so device memory holds one run's samples and STFT.
+
+    source(lo, hi) returns samples [lo, hi) of every channel as a (C, hi - lo) float64 tensor (read
+    from storage or generated in place); sink(lo, y) receives output samples [lo, lo + y.shape[1])
+    of every channel — consecutive runs in order, then the rank's first W - H samples once the
+    previous rank's overlap has arrived.  With sink=None the rank's output is returned as one tensor.
+    filt: a `vocoder_amd.filter.BoundFilter` of per-frame stages, or None for idFilter.
+
+    The synthesis chain of rank g starts from the phase advance of all ranks below it
+    (Vocoder.hs:190 is a running sum), which is known only after those ranks have analysed and
+    filtered their whole segments.  The STFT is not kept, so the segment is walked twice: once for
+    the advance alone (skipped on a single rank and for chains that leave every phase increment at
+    zero, Filter.hs:73), then, after the all-gather, for the output.  Within a rank the phases are
+    carried from run to run exactly as the reference carries them from frame to frame; overlap-add
+    across a run boundary adds the older run's partial sums first (Frames.hs:52-58), which
+    re-associates that sum of at most W/H terms by one rounding.
+
+    Returns (y or None, (ana_phase', syn_phase')) — the phases after the signal's last frame, the
+    same on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    world = dist.get_world_size(group) if multi else 1
+    rank = dist.get_rank(group) if multi else 0
+    chunk = par.H if chunk is None else chunk
+    sp = plan(par, length, world, rank, chunk)
+    F = sp.frames_total
+    if F == 0:           # shorter than one frame: nothing but the (empty or padded) overlap-add of no frames
+        x = source(0, 0)
+        y = torch.zeros((x.shape[0], sp.out_hi), dtype=torch.float64, device=x.device)
+        zero = torch.zeros((x.shape[0], par.K), dtype=torch.float64, device=x.device)
+        if sink is not None and sp.out_hi:
+            sink(0, y)
+        return (y if sink is None else None), (zero.clone() if ana_phase is None else ana_phase.clone(),
+                                               zero if syn_phase is None else syn_phase.clone())
+    runs = pieces_of(par, sp, piece_frames)
+    last_rank = rank == world - 1
+
+    def run_plan(i):
+        lo, hi = runs[i]
+        return _range_plan(par, F, lo, hi, sp.has_prev and i == 0, last_rank and i == len(runs) - 1, chunk, rank, world)
+
+    def analysed(i, carried):
+        pp = run_plan(i)
+        x = source(pp.in_lo, pp.in_hi)
+        assert x.shape[1] == pp.in_hi - pp.in_lo, (x.shape, pp)
+        mag, inc, ph = analyse(par, pp, x, carried)
+        mag, inc = _filtered(filt, mag, inc)
+        return pp, mag, inc, ph
+
+    total = None
+    if world > 1 and not _zero_increments(filt):
+        carried = ana_phase
+        for i in range(len(runs)):
+            _, _, inc, carried = analysed(i, carried)
+            if total is None:
+                total = torch.zeros((inc.shape[0], par.K), dtype=torch.float64, device=inc.device)
+            par._call("voc_phase_advance_dev", _ptr(inc), inc.shape[2], inc.shape[1], inc.shape[0], _ptr(total),
+                      _stream(inc))
+        totals = [torch.empty_like(total) for _ in range(world)]
+        dist.all_gather(totals, total, group=group)
+    else:
+        totals = None
+
+    held = None          # the rank's first samples, which still lack the previous rank's overlap
+    collected = [] if sink is None else None
+    carried, sph, tail = ana_phase, None, None
+    prev_tail = plan(par, length, world, rank - 1, chunk).tail if rank > 0 else 0
+    for i in range(len(runs)):
+        pp, mag, inc, carried = analysed(i, carried)
+        if sph is None:
+            if totals is not None:
+                sph = start_phase(totals, rank, syn_phase)
+            elif syn_phase is not None:
+                sph = syn_phase.clone()
+            else:
+                sph = torch.zeros((mag.shape[0], par.K), dtype=torch.float64, device=mag.device)
+        y, sph = synthesise(par, pp, mag, inc, sph)
+        if tail is not None:
+            add_incoming_tail(y, tail)
+        owned = pp.out_hi - pp.out_lo
+        tail = y[:, owned:].clone() if pp.tail else None
+        out, lo = y[:, :owned], pp.out_lo
+        if i == 0 and prev_tail:
+            held, out, lo = out[:, :prev_tail].clone(), out[:, prev_tail:], lo + prev_tail
+        if collected is not None:
+            collected.append(out)
+        elif out.shape[1]:
+            sink(lo, out)
+        del mag, inc, y
+
+    if world > 1:
+        reqs = []
+        if sp.tail:
+            reqs.append(dist.isend(tail.contiguous(), dist.get_global_rank(group, rank + 1) if group else rank + 1,
+                                   group=group))
+        tail_in = None
+        if prev_tail:
+            tail_in = torch.empty_like(held)
+            reqs.append(dist.irecv(tail_in, dist.get_global_rank(group, rank - 1) if group else rank - 1, group=group))
+        for r in reqs:
+            r.wait()
+        if tail_in is not None:
+            held = tail_in + held
+            if collected is not None:
+                collected.insert(0, held)
+            else:
+                sink(sp.out_lo, held)
+        last = dist.get_global_rank(group, world - 1) if group else world - 1
+        dist.broadcast(carried, last, group=group)
+        dist.broadcast(sph, last, group=group)
+    y_all = torch.cat(collected, dim=1) if collected is not None else None
+    return y_all, (carried, sph)
