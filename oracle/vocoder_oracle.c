@@ -66,8 +66,8 @@ static void fft_pow2(int n, double *re, double *im, int sign)
     /* twiddles exp(sign * 2 pi i k / n), k < n/2, rounded from long double; the table of
      * the last size used is kept (an FFT plan would hold it) */
     {
-        static int cached_n = 0;
-        static double *c_re = NULL, *c_im = NULL;
+        static __thread int cached_n = 0; /* per thread: the timing harness runs streams on several threads */
+        static __thread double *c_re = NULL, *c_im = NULL;
         if (cached_n != n) {
             free(c_re);
             free(c_im);
