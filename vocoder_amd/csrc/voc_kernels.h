@@ -53,6 +53,7 @@ struct ParamsT {
     const R *window;       // [W]
     const cplx<R> *twP;    // [M-1]    per-pass twiddles, see fft_passes
     const cplx<R> *twS;    // [M/2+1]  exp(-2 pi i k / N)
+    double omega1;         // 2 pi H / N when H and N are powers of two (the scaling is then exact), else 0
 };
 using Params = ParamsT<double>;
 
@@ -227,7 +228,7 @@ VOC_DEV double approx_rcp(double b)
 #endif
 }
 
-// a / b for b in [2^-4, 2^4], |a| <= b: hardware reciprocal seed, two Newton steps, one residual
+// a / b for b in [2^-4, 2^4], |a| <= b (and a = 0 with any normal b > 0): hardware reciprocal seed, two Newton steps, one residual
 // correction of the quotient.
 VOC_DEV double div_pos(double a, double b)
 {
@@ -252,22 +253,22 @@ VOC_DEV int frexp_exponent(double v)  // exponent e with |v| = m 2^e, 0.5 <= m <
 // sqrt(s) for s = 0 or 0.25 <= s < 2 (a sum of two squares of numbers scaled into [0, 1), the larger
 // one at least 0.5): reciprocal-square-root seed, one coupled Newton step on (sqrt, 1/(2 sqrt)), two
 // residual corrections -- the device library's own sequence without its rescaling of tiny
-// arguments and its special-case tests, neither of which can trigger on this domain.
-VOC_DEV double sqrt_scaled(double s, bool is_zero)
+// arguments and its special-case tests, neither of which can trigger on this domain.  For s = 0 the
+// seed is taken of a tiny positive number instead: it stays finite, every product with s is an
+// exact zero and the result is 0 without a test.
+VOC_DEV double sqrt_scaled(double s)
 {
 #ifdef VOC_EMU
-    (void)is_zero;
     return sqrt(s);
 #else
-    const double y = __builtin_amdgcn_rsq(s);
+    const double y = __builtin_amdgcn_rsq(fmax(s, 0x1p-1000));
     double g = s * y;
     double h = 0.5 * y;
     const double r = fma(-h, g, 0.5);
     g = fma(g, r, g);
     h = fma(h, r, h);
     g = fma(fma(-g, g, s), h, g);
-    g = fma(fma(-g, g, s), h, g);
-    return is_zero ? 0.0 : g;
+    return fma(fma(-g, g, s), h, g);
 #endif
 }
 
@@ -316,23 +317,27 @@ VOC_DEV double atan_poly(double t)
 // IEEE's.  q = min/max of the magnitudes is folded once, atan q = pi/4 + atan((q-1)/(q+1)) for
 // q > tan(pi/8), BEFORE the one division; then the octant is undone.  Finite inputs only: an
 // infinite or NaN component gives NaN.
+//
+// The zero bin needs no test of its own (a test the compiler turns into a branch around half of
+// the function, which keeps it from interleaving the chains of two bins): its divisor is replaced
+// by a tiny positive number, so q = 0, atan q = 0, and "x negative" is decided by x < 0, false for
+// -0.  The result is a zero with the sign of y (the reference's is +0 for every zero bin).
 VOC_DEV void hs_polar(double x, double y, double &mag, double &ph)
 {
     const double ax = fabs(x), ay = fabs(y);
     const int e = frexp_exponent(fmax(ax, ay));
     const double sx = ldexp(ax, -e), sy = ldexp(ay, -e);
     const double a = sx * sx, b = sy * sy;
-    const bool is_zero = ax == 0.0 && ay == 0.0;
-    mag = ldexp(sqrt_scaled(a + b, is_zero), e);
+    mag = ldexp(sqrt_scaled(a + b), e);
     const double mx = fmax(sx, sy), mn = fmin(sx, sy);
     const bool fold = mn > 0.41421356237309503 * mx;
     const double num = fold ? mn - mx : mn;
-    const double den = fold ? mn + mx : mx;
+    const double den = fmax(fold ? mn + mx : mx, 0x1p-1000);  // in [0.5, 2) unless the bin is zero
     double t = atan_poly(div_pos(num, den));
     t = fold ? t + 0.78539816339744828 : t;
     t = (ay > ax) ? 1.5707963267948966 - t : t;
-    t = __builtin_signbit(x) ? kPi - t : t;
-    ph = is_zero ? 0.0 : copysign(t, y);
+    t = (x < 0.0) ? kPi - t : t;
+    ph = copysign(t, y);
 }
 
 VOC_DEV double hs_magnitude(double x, double y)
@@ -488,20 +493,44 @@ VOC_DEV float hs_wrap(float e)
 }
 
 // calcPhaseInc (Vocoder.hs:169-173): omega = ((2 pi k) H) / N ; (omega + wrap (d - omega)) / H
+// With H and N powers of two, multiplying by H and by 1/N only moves the exponent, so one product
+// with the constant 2 pi H / N has the bits of ((2 pi k) H) / N.
+template <class R>
+VOC_DEV double bin_omega(const ParamsT<R> &p, int k)
+{
+    if (p.omega1 != 0.0) return (double)k * p.omega1;
+    asm volatile("");  // keeps this (uniform) branch a branch: as a select both sides would be computed
+    return ((kTwoPi * (double)k) * (double)p.hop_d) * (double)p.inv_n;
+}
+
 VOC_DEV double phase_inc(const ParamsT<double> &p, int k, double ph_diff)
 {
-    const double omega = ((kTwoPi * (double)k) * p.hop_d) * p.inv_n;
+    const double omega = bin_omega(p, k);
     const double s = omega + hs_wrap(ph_diff - omega);
     return p.hop_pow2 ? s * p.inv_hop : s / p.hop_d;
+}
+
+// The same for callers that know at compile time that H and N are powers of two (the bits are
+// those of phase_inc; the two uniform branches are gone).
+VOC_DEV double phase_inc_pow2(const ParamsT<double> &p, int k, double ph_diff)
+{
+    const double omega = (double)k * p.omega1;
+    return (omega + hs_wrap(ph_diff - omega)) * p.inv_hop;
+}
+
+VOC_DEV float phase_inc_pow2(const ParamsT<float> &p, int k, float ph_diff)
+{
+    const double omega = (double)k * p.omega1;
+    return (float)((omega + hs_wrap((double)ph_diff - omega)) * (double)p.inv_hop);
 }
 
 // float variant: omega reaches thousands of radians, so the sum is formed in double (a float
 // 2 pi alone would bias every frame's increment by omega * 3e-8) and rounded to float once.
 VOC_DEV float phase_inc(const ParamsT<float> &p, int k, float ph_diff)
 {
-    const double omega = ((kTwoPi * (double)k) * (double)p.hop_d) * (double)p.inv_n;
+    const double omega = bin_omega(p, k);
     const double s = omega + hs_wrap((double)ph_diff - omega);
-    return (float)(s / (double)p.hop_d);
+    return (float)(p.hop_pow2 ? s * (double)p.inv_hop : s / (double)p.hop_d);
 }
 
 // analysisStep for one bin (Vocoder.hs:158-163).  `prev` is replaced by the new raw phase.

@@ -371,8 +371,13 @@ VOC_UNROLL(VOC_POLAR_UNROLL)
             if (emit) {
                 mrow[pe] = ma * half_vol;
                 mrow[q] = mb * half_vol;
-                irow[pe] = phase_inc(p, pe, pha - pa);
-                irow[q] = phase_inc(p, q, phb - pb);
+                if constexpr (SLIDE > 0) {  // H = SLIDE * N/8: a power of two, like N
+                    irow[pe] = phase_inc_pow2(p, pe, pha - pa);
+                    irow[q] = phase_inc_pow2(p, q, phb - pb);
+                } else {
+                    irow[pe] = phase_inc(p, pe, pha - pa);
+                    irow[q] = phase_inc(p, q, phb - pb);
+                }
             }
             php[pe] = pha;
             php[q] = phb;
@@ -387,7 +392,7 @@ VOC_UNROLL(VOC_POLAR_UNROLL)
             const R phr = xr < (R)0 ? (R)kPi : (R)0;
             if (emit) {
                 mrow[kb] = fabs(xr) * a.vol;
-                irow[kb] = phase_inc(p, kb, phr - php[kb]);
+                irow[kb] = SLIDE > 0 ? phase_inc_pow2(p, kb, phr - php[kb]) : phase_inc(p, kb, phr - php[kb]);
             }
             php[kb] = phr;
         }

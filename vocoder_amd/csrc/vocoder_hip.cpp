@@ -825,6 +825,7 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
         p.hop_d = (double)H;
         p.inv_hop = 1.0 / (double)H;
         p.inv_n = 1.0 / (double)N;
+        p.omega1 = (p.hop_pow2 && !chirp) ? (voc::kTwoPi * (double)H) / (double)N : 0.0;  // exact scalings of 2 pi
         p.window = c->d_window;
         p.twP = c->d_twP;
         p.twS = c->d_twS;
@@ -896,7 +897,7 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
             HIPCHK(hipMemcpy(c->d_twS_f, tsf.data(), sizeof(float2) * tsf.size(), hipMemcpyHostToDevice));
             voc::ParamsT<float> &q = c->params_f;
             q.N = N; q.W = W; q.H = H; q.K = c->K; q.M = c->M;
-            q.hd = p.hd; q.off = p.off; q.hop_pow2 = p.hop_pow2;
+            q.hd = p.hd; q.off = p.off; q.hop_pow2 = p.hop_pow2; q.omega1 = p.omega1;
             q.hop_d = (float)H;
             q.inv_hop = 1.0f / (float)H;
             q.inv_n = 1.0f / (float)N;
