@@ -81,6 +81,17 @@ foreign import ccall unsafe "voc_play_speed_frames" c_voc_play_speed_frames :: I
 foreign import ccall unsafe "voc_play_speed_map"    c_voc_play_speed_map
     :: Int64 -> Int64 -> Int64 -> Ptr Int64 -> Int64 -> IO Int32
 
+-- * Interleaved and 16-bit PCM device buffers at the file edge (device pointers; Audio.hs:51-55,
+--   VocoderFile.hs:158,168-173)
+foreign import ccall safe   "voc_deinterleave_dev"    c_voc_deinterleave_dev
+    :: Ptr VocCtx -> Ptr Double -> Int64 -> Int64 -> Ptr Double -> Int64 -> Ptr () -> IO Int32
+foreign import ccall safe   "voc_interleave_dev"      c_voc_interleave_dev
+    :: Ptr VocCtx -> Ptr Double -> Int64 -> Int64 -> Int64 -> Ptr Double -> Ptr () -> IO Int32
+foreign import ccall safe   "voc_pcm16_to_planar_dev" c_voc_pcm16_to_planar_dev
+    :: Ptr VocCtx -> Ptr Int16 -> Int64 -> Int64 -> Ptr Double -> Int64 -> Ptr () -> IO Int32
+foreign import ccall safe   "voc_planar_to_pcm16_dev" c_voc_planar_to_pcm16_dev
+    :: Ptr VocCtx -> Ptr Double -> Int64 -> Int64 -> Int64 -> Int32 -> Ptr Int16 -> Ptr () -> IO Int32
+
 -- * Chunk-at-a-time streaming (Vocoder.Conduit.process as a conduit)
 
 data VocStream

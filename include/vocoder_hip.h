@@ -281,6 +281,21 @@ int32_t voc_deinterleave_dev(voc_ctx *ctx, const double *inter, int64_t n, int64
 int32_t voc_interleave_dev(voc_ctx *ctx, const double *planar, int64_t stride, int64_t n, int64_t channels,
                            double *inter, void *stream);
 
+/* ---- 16-bit PCM at the file edge ------------------------------------------------------------------
+ * vocoder-file reads its sources with sourceSnd and writes WAV / PCM16 with sinkSnd
+ * (vocoder-audio/example/VocoderFile.hs:158,168-173), i.e. through libsndfile's double interface.
+ * These two calls do that conversion on interleaved device buffers, fused with the
+ * (de)interleave: reading, planar[c*stride + i] = inter[i*channels + c] / 32768; writing,
+ * inter[i*channels + c] = lrint(x * 32767) kept to its low 16 bits (clip == 0, libsndfile's default) or
+ * lrint(x * 32768) saturated to [-32768, 32767] (clip != 0, its SFC_SET_CLIPPING mode); halves round to
+ * even.  libsndfile is outside the reference tree: the convention is restated from its published
+ * source and is not pinned by any vector of the reference.
+ */
+int32_t voc_pcm16_to_planar_dev(voc_ctx *ctx, const int16_t *inter, int64_t n, int64_t channels, double *planar,
+                                int64_t stride, void *stream);
+int32_t voc_planar_to_pcm16_dev(voc_ctx *ctx, const double *planar, int64_t stride, int64_t n, int64_t channels,
+                                int32_t clip, int16_t *inter, void *stream);
+
 /* ---- chunk-at-a-time streaming (Vocoder.Conduit.process as a conduit, Conduit.hs:46-53) --------
  * A voc_stream holds what the reference's conduits hold between chunks: the samples
  * genFramesOfE has not consumed (Frames.hs:36-37), the analysis and synthesis phases

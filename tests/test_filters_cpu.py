@@ -183,3 +183,34 @@ def test_interleaved_framing_equals_planar_per_channel(par, orc):
         fr_ch, left_ch = orc.gen_frames_of_e(128, 32, [planar[ch]])
         assert np.array_equal(fr_inter.reshape(-1, 128, c)[:, :, ch], fr_ch)
         assert np.array_equal(left.reshape(-1, c)[:, ch], left_ch)
+
+
+def _pcm16_expected(x, clip):
+    """libsndfile's double -> short conversions, restated with numpy (rint rounds halves to even)."""
+    if clip:
+        v = x * 32768.0
+        r = np.rint(np.clip(v, -32768.0, 32767.0))
+        return np.where(v >= 32767.0, 32767, np.where(v <= -32768.0, -32768, r)).astype(np.int64).astype(np.int16)
+    return (np.rint(x * 32767.0).astype(np.int64) & 0xffff).astype(np.uint16).view(np.int16)
+
+
+def test_pcm16_edge_matches_the_libsndfile_convention(par):
+    """File-edge conversions (parity unpinned: libsndfile is not part of the reference tree; the
+    expected values restate its documented conversions)."""
+    import torch
+    from vocoder_amd import conduit as Cd
+    rng = np.random.default_rng(3)
+    c, n = 3, 1000
+    pcm = rng.integers(-32768, 32768, n * c, dtype=np.int16)
+    pcm[:4] = [-32768, 32767, 0, -1]
+    planar = Cd.pcm16_to_planar_dev(par, torch.from_numpy(pcm), c).numpy()
+    assert np.array_equal(planar, pcm.reshape(n, c).T.astype(np.float64) / 32768.0)
+    x = rng.uniform(-1.2, 1.2, (c, n))
+    x[0, :8] = [0.5 / 32767, 1.5 / 32767, 2.5 / 32767, -0.5 / 32767, 1.0, -1.0, 1.00002, -1.00004]   # ties, full scale, overflow
+    x[1, :4] = [0.5 / 32768, 1.5 / 32768, 32766.5 / 32768, -32767.5 / 32768]
+    for clip in (False, True):
+        got = Cd.planar_to_pcm16_dev(par, torch.from_numpy(x), clip).numpy()
+        assert np.array_equal(got.reshape(n, c).T, _pcm16_expected(x, clip)), clip
+    # a file read and written back without processing: s/32768 * 32767 rounds back to s except towards full scale
+    back = Cd.planar_to_pcm16_dev(par, torch.from_numpy(planar), False).numpy()
+    assert np.abs(back.astype(np.int32) - pcm.astype(np.int32)).max() <= 1

@@ -127,3 +127,23 @@ def test_filtered_pipeline_matches_oracle(gpu_lib, orc, n, hop, chain, speed):
         assert y.shape[1] == ref["y"].size
         err = np.linalg.norm(y[ch] - ref["y"]) / np.linalg.norm(ref["y"])
         assert err <= TOL_L2, err
+
+
+def test_pcm16_edge_on_device(gpu_lib):
+    """16-bit PCM <-> planar doubles on the GPU against the numpy restatement of libsndfile's
+    conversions (parity unpinned: libsndfile is outside the reference tree)."""
+    import torch
+    from vocoder_amd import vocoder as V, conduit as Cd
+    from test_filters_cpu import _pcm16_expected
+    par = V.VocoderParams(256, 64, _hann(256), lib=gpu_lib)
+    rng = np.random.default_rng(8)
+    c, n = 2, 100003
+    pcm = rng.integers(-32768, 32768, n * c, dtype=np.int16)
+    planar = Cd.pcm16_to_planar_dev(par, torch.from_numpy(pcm).cuda(), c)
+    assert np.array_equal(planar.cpu().numpy(), pcm.reshape(n, c).T.astype(np.float64) / 32768.0)
+    x = rng.uniform(-1.1, 1.1, (c, n))
+    x[0, :6] = [0.5 / 32767, 1.5 / 32767, -2.5 / 32767, 1.0, -1.0, 1.00002]
+    x[1, :4] = [0.5 / 32768, 1.5 / 32768, 32766.5 / 32768, -32767.5 / 32768]
+    for clip in (False, True):
+        got = Cd.planar_to_pcm16_dev(par, torch.from_numpy(x).cuda(), clip).cpu().numpy()
+        assert np.array_equal(got.reshape(n, c).T, _pcm16_expected(x, clip)), clip

@@ -59,6 +59,8 @@ SIGNATURES = {
     "voc_gather_frames_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
     "voc_deinterleave_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _vp]),
     "voc_interleave_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "voc_pcm16_to_planar_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _vp]),
+    "voc_planar_to_pcm16_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp]),
     "voc_stream_create": (_i32, [_vp, _i64, _i64, _vp, C.POINTER(_vp)]),
     "voc_stream_create_mode": (_i32, [_vp, _i64, _i64, _vp, _i32, C.POINTER(_vp)]),
     "voc_stream_set_filter": (_i32, [_vp, _vp]),

@@ -16,7 +16,7 @@ import numpy as np
 from .vocoder import VocoderParams, _f64, _p, zero_phase
 
 __all__ = ["num_frames", "leftover_length", "ola_length", "frames_of_e", "sum_frames_e", "process_with",
-           "process", "process_dev", "roundtrip_workspace_bytes", "process_filter_dev", "deinterleave_dev", "interleave_dev"]
+           "process", "process_dev", "roundtrip_workspace_bytes", "process_filter_dev", "deinterleave_dev", "interleave_dev", "pcm16_to_planar_dev", "planar_to_pcm16_dev"]
 
 
 def num_frames(par: VocoderParams, length: int) -> int:
@@ -175,4 +175,29 @@ def interleave_dev(par: VocoderParams, planar):
     out = torch.empty(n * c, dtype=torch.float64, device=planar.device)
     st = C.c_void_p(torch.cuda.current_stream(planar.device).cuda_stream) if planar.is_cuda else None
     par._call("voc_interleave_dev", C.c_void_p(planar.data_ptr()), planar.stride(0), n, c, C.c_void_p(out.data_ptr()), st)
+    return out
+
+
+def pcm16_to_planar_dev(par: VocoderParams, inter, channels: int):
+    """Interleaved int16 samples (n*channels,) -> planar float64 (channels, n) the way the reference's
+    sourceSnd hands them over (libsndfile: s / 32768; VocoderFile.hs:172)."""
+    import torch
+    assert inter.dtype == torch.int16 and inter.is_contiguous()
+    n = inter.numel() // channels
+    out = torch.empty((channels, n), dtype=torch.float64, device=inter.device)
+    st = C.c_void_p(torch.cuda.current_stream(inter.device).cuda_stream) if inter.is_cuda else None
+    par._call("voc_pcm16_to_planar_dev", C.c_void_p(inter.data_ptr()), n, channels, C.c_void_p(out.data_ptr()), n, st)
+    return out
+
+
+def planar_to_pcm16_dev(par: VocoderParams, planar, clip: bool = False):
+    """Planar float64 (channels, n) -> interleaved int16 (n*channels,) the way sinkSnd writes PCM16
+    (VocoderFile.hs:158,173; libsndfile: lrint(x * 32767), or with clip lrint(x * 32768) saturated)."""
+    import torch
+    assert planar.dtype == torch.float64 and planar.stride(-1) == 1
+    c, n = planar.shape
+    out = torch.empty(n * c, dtype=torch.int16, device=planar.device)
+    st = C.c_void_p(torch.cuda.current_stream(planar.device).cuda_stream) if planar.is_cuda else None
+    par._call("voc_planar_to_pcm16_dev", C.c_void_p(planar.data_ptr()), planar.stride(0), n, c, 1 if clip else 0,
+              C.c_void_p(out.data_ptr()), st)
     return out

@@ -981,6 +981,39 @@ __global__ void interleave_kernel(const double *__restrict__ planar, long long s
         for (int c = 0; c < channels; ++c) inter[i * channels + c] = planar[c * stride + i];
 }
 
+// 16-bit PCM at the file edge.  The reference reads and writes sound files through libsndfile's
+// double interface (sourceSnd / sinkSnd, vocoder-audio/example/VocoderFile.hs:158,168-173): a
+// 16-bit sample s is read as s / 32768; a double x is written as lrint(x * 32767) kept to its low
+// 16 bits (libsndfile's default), or, with clipping requested, as lrint(x * 32768) saturated to
+// [-32768, 32767].  lrint rounds halves to even.
+__global__ void pcm16_to_planar_kernel(const short *__restrict__ inter, long long n, int channels,
+                                       double *__restrict__ planar, long long stride)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        for (int c = 0; c < channels; ++c) planar[c * stride + i] = (double)inter[i * channels + c] * 0x1p-15;
+}
+
+VOC_DEV short pcm16_of(double x, bool clip)
+{
+    if (clip) {
+        const double v = x * 32768.0;
+        if (v >= 32767.0) return (short)32767;
+        if (v <= -32768.0) return (short)-32768;
+        return (short)(long long)rint(v);
+    }
+    const double v = rint(x * 32767.0);
+    // the low 16 bits of the integer: exact for |v| < 2^62, anything beyond (or NaN) gives 0
+    const long long w = (fabs(v) < 0x1p62) ? (long long)v : 0;
+    return (short)(unsigned short)((unsigned long long)w & 0xffffull);
+}
+
+__global__ void planar_to_pcm16_kernel(const double *__restrict__ planar, long long stride, long long n, int channels,
+                                       int clip, short *__restrict__ inter)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        for (int c = 0; c < channels; ++c) inter[i * channels + c] = pcm16_of(planar[c * stride + i], clip != 0);
+}
+
 // ------------------------------------------------------------------ step-level, framing, overlap-add
 
 // analysisStep over B independent frames (Vocoder.hs:158-163)
