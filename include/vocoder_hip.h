@@ -204,6 +204,20 @@ int32_t voc_synthesis_signal_dev(voc_ctx *ctx, const double *mag, const double *
 int32_t voc_phase_advance_dev(voc_ctx *ctx, const double *ph_inc, int64_t ldk, int64_t nframes, int64_t channels,
                               double *phase_io, void *stream);
 
+/* voc_synthesis_signal_dev reading its frames through row maps: output frame j of a channel takes
+ * its moduli from row mag_rows[j] of that channel's mag_frames rows of `mag`, its increments from
+ * row inc_rows[j] of the inc_frames rows of `ph_inc` (device arrays of nframes indices; entries are
+ * clamped into their array).  This is playSpeed (Conduit/Filter.hs:122-136: every frame emitted
+ * zero or more times) feeding synthesis without the copy voc_gather_frames_dev makes.  A NULL map
+ * means row j, and that array then holds exactly nframes rows per channel.  The two maps are
+ * separate because a filter that follows playSpeed may rewrite one array per output frame and
+ * leave the other alone (randomPhaseFilter, Filter.hs:156-157).
+ */
+int32_t voc_synthesis_mapped_dev(voc_ctx *ctx, const double *mag, int64_t mag_frames, const int64_t *mag_rows,
+                                 const double *ph_inc, int64_t inc_frames, const int64_t *inc_rows, int64_t ldk,
+                                 int64_t nframes, int64_t channels, double *phase_io, double *y, int64_t y_stride,
+                                 int64_t y_len, void *stream);
+
 /* ---- frequency-domain filters (vocoder/src/Vocoder/Filter.hs) -----------------------------------
  * A voc_filter is a chain in composeFilters order (Filter.hs:54-55; vocoder-file folds its
  * command-line filters the same way, vocoder-audio/example/VocoderFile.hs:72); an empty chain
@@ -251,6 +265,9 @@ enum {
 int32_t voc_filter_create(voc_ctx *ctx, double freq_step, voc_filter **out);
 int32_t voc_filter_destroy(voc_filter *f);
 int32_t voc_filter_length(const voc_filter *f);
+/* flags4 <- {reads mag, writes mag, reads ph_inc, writes ph_inc} for the chain as a whole (an array
+ * the chain neither reads nor writes is never touched by voc_filter_apply_dev) */
+int32_t voc_filter_touches(const voc_filter *f, int32_t *flags4);
 int32_t voc_filter_append(voc_filter *f, int32_t kind, const double *params, int32_t nparams);
 int32_t voc_filter_apply(voc_filter *f, double *mag, double *ph_inc, int64_t nframes, int64_t channels);
 int32_t voc_filter_apply_dev(voc_filter *f, double *mag, double *ph_inc, int64_t ldk, int64_t nframes,

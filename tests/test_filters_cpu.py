@@ -214,3 +214,78 @@ def test_pcm16_edge_matches_the_libsndfile_convention(par):
     # a file read and written back without processing: s/32768 * 32767 rounds back to s except towards full scale
     back = Cd.planar_to_pcm16_dev(par, torch.from_numpy(planar), False).numpy()
     assert np.abs(back.astype(np.int32) - pcm.astype(np.int32)).max() <= 1
+
+
+def _mapped_vs_gathered(lib, n, hop, c, f_in, coeff, monkeypatch, syn_tile=0, slots=None, device=None):
+    """voc_synthesis_mapped_dev against voc_gather_frames_dev + voc_synthesis_signal_dev: same bits."""
+    import torch
+    from vocoder_amd import vocoder as V, filter as Fl
+    monkeypatch.setenv("VOC_SYN_TILE_LEN", str(syn_tile))
+    if slots:
+        monkeypatch.setenv("VOC_SYN_SLOTS", str(slots))
+    else:
+        monkeypatch.delenv("VOC_SYN_SLOTS", raising=False)
+    par = V.VocoderParams(n, hop, _hann(n), lib=lib)
+    ldk = (par.K + 1) & ~1
+    rng = np.random.default_rng(12)
+    dev = device or "cpu"
+    mag = torch.from_numpy(rng.uniform(0, 1, (c, f_in, ldk))).to(dev)
+    inc = torch.from_numpy(rng.uniform(-0.02, 0.02, (c, f_in, ldk))).to(dev)
+    src = torch.from_numpy(Fl.play_speed_map(par, coeff, f_in)).to(dev)
+    fo = src.numel()
+    ylen = (fo - 1) * hop + n
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream) if dev != "cpu" else None
+    ph0 = torch.from_numpy(rng.uniform(-3, 3, (c, par.K))).to(dev)
+
+    def run(mag_t, mrows, inc_t, irows):
+        ph, y = ph0.clone(), torch.empty((c, ylen), dtype=torch.float64, device=dev)
+        par._call("voc_synthesis_mapped_dev", p(mag_t), mag_t.shape[1], p(mrows), p(inc_t), inc_t.shape[1], p(irows), ldk,
+                  fo, c, p(ph), p(y), ylen, ylen, st)
+        return y, ph
+
+    mg, ig = mag[:, src].contiguous(), inc[:, src].contiguous()
+    ph, y = ph0.clone(), torch.empty((c, ylen), dtype=torch.float64, device=dev)
+    par._call("voc_synthesis_signal_dev", p(mg), p(ig), ldk, fo, c, p(ph), p(y), ylen, ylen, st)
+    for args in ((mag, src, inc, src), (mg, None, inc, src), (mag, src, ig, None), (mg, None, ig, None)):
+        y2, ph2 = run(*args)
+        assert torch.equal(y2, y) and torch.equal(ph2, ph), [a is None for a in args]
+    # entries outside the array are clamped into it, never followed
+    wild = src.clone()
+    wild[0], wild[-1] = -7, 10 ** 12
+    y3, _ = run(mag, wild, inc, wild)
+    y4, _ = run(mag, wild.clamp(0, f_in - 1), inc, wild.clamp(0, f_in - 1))
+    assert torch.equal(y3, y4)
+    d = par.lib.dll
+    assert d.voc_synthesis_mapped_dev(par.handle, p(mag), f_in, None, p(inc), f_in, p(src), ldk, fo, c, p(ph), p(y), ylen,
+                                      ylen, st) == (-5 if fo != f_in else 0)      # no map: the array must hold nframes rows
+    assert d.voc_synthesis_mapped_dev(par.handle, p(mag), 0, p(src), p(inc), f_in, p(src), ldk, fo, c, p(ph), p(y), ylen,
+                                      ylen, st) == -5
+
+
+@pytest.mark.parametrize("n,hop,tile,slots", [(128, 32, 0, None), (128, 32, 5, None), (1024, 256, 4, 2), (1024, 256, 0, 2)])
+def test_mapped_synthesis_equals_gather_then_synthesis(emu_lib, monkeypatch, n, hop, tile, slots):
+    _mapped_vs_gathered(emu_lib, n, hop, 3, 9, Fraction(2), monkeypatch, tile, slots)
+    _mapped_vs_gathered(emu_lib, n, hop, 3, 11, Fraction(2, 3), monkeypatch, tile, slots)
+
+
+def test_play_speed_then_filters_lazy_equals_eager(par, emu_lib):
+    """A chain after playSpeed gathers only the array it reads: random_phase gets a fresh ph_inc
+    and leaves the moduli mapped; a gain gathers the moduli and leaves ph_inc mapped."""
+    import torch
+    from vocoder_amd import filter as Fl
+    mag, inc = (torch.from_numpy(a) for a in _stft(par, c=2, f=7, seed=4))
+    ldk = (par.K + 1) & ~1
+    pad = lambda t: torch.nn.functional.pad(t, (0, ldk - par.K)).contiguous()
+    mag, inc = pad(mag), pad(inc)
+    for descr, lazy_mag, lazy_inc in (
+            (Fl.play_speed(2) >> Fl.random_phase_filter(5), True, False),
+            (Fl.play_speed(Fraction(3, 2)) >> Fl.amplify(0.25), False, True),
+            (Fl.amplify(2.0) >> Fl.play_speed(2) >> Fl.play_speed(Fraction(1, 3)), True, True),
+            (Fl.play_speed(2) >> Fl.pitch_shift_interpolate(1.5), False, False)):
+        b = descr.bind(par, 375.0)
+        me, ie = b.apply_dev(mag.clone(), inc.clone())
+        ml, mr, il, ir, fo = b.apply_dev_lazy(mag.clone(), inc.clone())
+        assert (mr is not None) == lazy_mag and (ir is not None) == lazy_inc and fo == me.shape[1]
+        assert torch.equal(ml if mr is None else ml[:, mr], me)
+        assert torch.equal(il if ir is None else il[:, ir], ie)

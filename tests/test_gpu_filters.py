@@ -147,3 +147,13 @@ def test_pcm16_edge_on_device(gpu_lib):
     for clip in (False, True):
         got = Cd.planar_to_pcm16_dev(par, torch.from_numpy(x).cuda(), clip).cpu().numpy()
         assert np.array_equal(got.reshape(n, c).T, _pcm16_expected(x, clip)), clip
+
+
+@pytest.mark.parametrize("n,hop,c,f_in,coeff,tile", [(4096, 1024, 5, 40, Fraction(2), 0), (4096, 1024, 5, 40, Fraction(2, 3), 7),
+                                                    (8192, 2048, 3, 21, Fraction(2), 0), (256, 64, 4, 33, Fraction(5, 3), 6),
+                                                    (16384, 4096, 2, 9, Fraction(2), 3)])
+def test_mapped_synthesis_equals_gather_then_synthesis(gpu_lib, monkeypatch, n, hop, c, f_in, coeff, tile):
+    """playSpeed through row maps (no copy) against the gathered STFT, bit for bit, in the
+    specialised, the generic and the frames-in-memory synthesis kernels, whole and tiled."""
+    from test_filters_cpu import _mapped_vs_gathered
+    _mapped_vs_gathered(gpu_lib, n, hop, c, f_in, coeff, monkeypatch, tile, None, device="cuda")

@@ -56,6 +56,8 @@ SIGNATURES = {
     "voc_filter_apply_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "voc_play_speed_frames": (_i64, [_i64, _i64, _i64]),
     "voc_play_speed_map": (_i32, [_i64, _i64, _i64, _vp, _i64]),
+    "voc_synthesis_mapped_dev": (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _vp]),
+    "voc_filter_touches": (_i32, [_vp, _vp]),
     "voc_gather_frames_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
     "voc_deinterleave_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _vp]),
     "voc_interleave_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),

@@ -146,14 +146,20 @@ def process_filter_dev(par: VocoderParams, filt, x, length: int | None = None, c
     if f:
         par._call("voc_analysis_signal_dev", C.c_void_p(x.data_ptr()), x.stride(0), f, c, C.c_void_p(aph.data_ptr()),
                   C.c_void_p(mag.data_ptr()), C.c_void_p(inc.data_ptr()), ldk, 1, st)
+    mrows = irows = None
+    fo = f
     if filt is not None:
-        mag, inc = filt.apply_dev(mag, inc)
-    fo = mag.shape[1]
+        mag, mrows, inc, irows, fo = filt.apply_dev_lazy(mag, inc)
     n = ola_length(par, fo, chunk)
     y = torch.empty((c, n), dtype=torch.float64, device=dev)
-    if fo:
+    if fo and mrows is None and irows is None:
         par._call("voc_synthesis_signal_dev", C.c_void_p(mag.data_ptr()), C.c_void_p(inc.data_ptr()), ldk, fo, c,
                   C.c_void_p(sph.data_ptr()), C.c_void_p(y.data_ptr()), y.stride(0), n, st)
+    elif fo:   # play_speed: synthesis reads the rows through the maps, nothing is copied
+        par._call("voc_synthesis_mapped_dev", C.c_void_p(mag.data_ptr()), mag.shape[1],
+                  C.c_void_p(mrows.data_ptr()) if mrows is not None else None,
+                  C.c_void_p(inc.data_ptr()), inc.shape[1], C.c_void_p(irows.data_ptr()) if irows is not None else None,
+                  ldk, fo, c, C.c_void_p(sph.data_ptr()), C.c_void_p(y.data_ptr()), y.stride(0), n, st)
     return y, aph, sph
 
 

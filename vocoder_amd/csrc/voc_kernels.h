@@ -720,8 +720,37 @@ struct SynArgsT {
     long long F;
     int tile_len, tiles, halo;
     long long unsplit;        // the first `unsplit` channels run as one tile each (no carry); the others in `tiles` tiles
+    // Optional frame maps (playSpeed without a copy): frame f of a channel takes its moduli from row
+    // mag_rows[f] of that channel's F_mag rows, its increments from row inc_rows[f] of F_inc rows.
+    // Null map: row f; F_mag / F_inc of 0: F.
+    const long long *mag_rows, *inc_rows;
+    long long F_mag, F_inc;
 };
 using SynArgs = SynArgsT<double>;
+
+// Row index of frame f of channel c in an array of `rows_per_channel` rows per channel, through an
+// optional map whose entries are clamped into the array (a bad entry reads a wrong row, never
+// outside the array).
+VOC_DEV long long mapped_row(long long c, long long f, const long long *map, long long rows_per_channel, long long F)
+{
+    const long long n = rows_per_channel ? rows_per_channel : F;
+    long long r = f;
+    if (map) {
+        r = map[f];
+        r = r < 0 ? 0 : (r >= n ? n - 1 : r);
+    }
+    return c * n + r;
+}
+template <class R>
+VOC_DEV const R *mag_row_of(const SynArgsT<R> &a, long long c, long long f)
+{
+    return a.mag + mapped_row(c, f, a.mag_rows, a.F_mag, a.F) * a.ldk;
+}
+template <class R>
+VOC_DEV const R *inc_row_of(const SynArgsT<R> &a, long long c, long long f)
+{
+    return a.inc + mapped_row(c, f, a.inc_rows, a.F_inc, a.F) * a.ldk;
+}
 
 template <int LOG2M, int IN_MODE, int OUT_MODE, class R = double>
 __global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) synthesis_kernel(ParamsT<R> p, SynArgsT<R> a)
@@ -763,6 +792,11 @@ __global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) synthesis_kernel(ParamsT<R> 
 
     for (long long f = fs; f < f1; ++f) {
         const long long row = c * a.F + f;
+        const R *mrow = nullptr, *irow = nullptr;
+        if (IN_MODE == SYN_IN_POLAR) {
+            mrow = mag_row_of(a, c, f);
+            irow = inc_row_of(a, c, f);
+        }
         // ---- spectrum of this frame -> half-length complex input Z (stored re<->im swapped so
         //      that the forward FFT below performs the backward transform)
 #pragma unroll
@@ -771,8 +805,8 @@ __global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) synthesis_kernel(ParamsT<R> 
             if (pr < M / 2) {
                 C2 A, B;  // X[pr], X[M - pr]
                 if (IN_MODE == SYN_IN_POLAR) {
-                    A = synthesize_bin(p, a.mag[row * a.ldk + pr], a.inc[row * a.ldk + pr], ph[2 * m]);
-                    B = synthesize_bin(p, a.mag[row * a.ldk + (M - pr)], a.inc[row * a.ldk + (M - pr)], ph[2 * m + 1]);
+                    A = synthesize_bin(p, mrow[pr], irow[pr], ph[2 * m]);
+                    B = synthesize_bin(p, mrow[M - pr], irow[M - pr], ph[2 * m + 1]);
                 } else {
                     const R *s = a.spec + row * 2 * p.K;
                     A = mk2(s[2 * pr], s[2 * pr + 1]);
@@ -793,7 +827,7 @@ __global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) synthesis_kernel(ParamsT<R> 
         if (own_half) {
             C2 A;
             if (IN_MODE == SYN_IN_POLAR) {
-                A = synthesize_bin(p, a.mag[row * a.ldk + M / 2], a.inc[row * a.ldk + M / 2], ph[2 * NP]);
+                A = synthesize_bin(p, mrow[M / 2], irow[M / 2], ph[2 * NP]);
             } else {
                 const R *s = a.spec + row * 2 * p.K;
                 A = mk2(s[M], s[M + 1]);
@@ -894,13 +928,27 @@ __global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) synthesis_kernel(ParamsT<R> 
 template <class R>
 __global__ void phase_carry_kernel(ParamsT<R> p, const R *__restrict__ inc, long long ldk, long long F,
                                    const R *__restrict__ phase_in, R *__restrict__ carry, int tile_len,
-                                   int tiles, int halo, long long channels)
+                                   int tiles, int halo, long long channels, const long long *__restrict__ rows,
+                                   long long F_inc)
 {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= channels * p.K) return;
     const long long c = g / p.K;
     const int k = (int)(g % p.K);
     R ph = phase_in[c * p.K + k];
+    if (rows) {  // frames through a map (`inc` then points at the first of these channels' F_inc rows each)
+        long long next = (long long)tile_len - halo;
+        int t = 1;
+        for (long long f = 0; f < F && t < tiles; ++f) {
+            ph = phase_step(ph, inc[mapped_row(c, f, rows, F_inc, F) * ldk + k] * p.hop_d);
+            if (f + 1 == next) {
+                carry[(c * tiles + t) * p.K + k] = ph;
+                ++t;
+                next += tile_len;
+            }
+        }
+        return;
+    }
     const R *src = inc + c * F * ldk + k;
     long long next = (long long)tile_len - halo;  // frame count after which tile 1 starts
     int t = 1;

@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(Cfg<LOG2L>::T) synthesis_blue_kernel(Params p,
             if (k < p.K) {
                 double2 A;
                 if (IN_MODE == SYN_IN_POLAR) {
-                    A = synthesize_bin(p, a.mag[row * a.ldk + k], a.inc[row * a.ldk + k], ph[q]);
+                    A = synthesize_bin(p, mag_row_of(a, c, f)[k], inc_row_of(a, c, f)[k], ph[q]);
                 } else {
                     const double *s = a.spec + row * 2 * p.K;
                     A = make_double2(s[2 * k], s[2 * k + 1]);

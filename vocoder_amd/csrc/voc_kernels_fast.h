@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
     // STFT row of frame f: (mag, ph_inc) of this thread's eight bins, plus DC / Nyquist for thread 0
     R mg[8], ic[8], mg0 = (R)0, mgm = (R)0, ic0 = (R)0, icm = (R)0;
     auto load_row = [&](long long f, int lt) {
-        const R *mrow = a.mag + (c * a.F + f) * a.ldk, *irow = a.inc + (c * a.F + f) * a.ldk;
+        const R *mrow = mag_row_of(a, c, f), *irow = inc_row_of(a, c, f);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const unsigned pr = lt + m * T;

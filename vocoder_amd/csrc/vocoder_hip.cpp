@@ -430,7 +430,8 @@ void synthesis_stage_dev(voc_ctx *c, double *phase_io, const double *mag, const 
         const long long chains = C * c->K;
         LaunchTimer timer(c, KIND_CARRY, st);
         hipLaunchKernelGGL(voc::phase_carry_kernel<double>, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st,
-                           c->params, inc, (long long)c->K, F, pin, carry, tile_len, tiles, 0, C);
+                           c->params, inc, (long long)c->K, F, pin, carry, tile_len, tiles, 0, C,
+                           (const long long *)nullptr, 0LL);
         HIPCHK(hipGetLastError());
     }
     voc::SynArgs a{};
@@ -479,7 +480,9 @@ constexpr size_t kLdsLimit = 160 * 1024;
 long long synthesis_unsplit(const voc_ctx *c, long long channels, long long F, int halo, bool fused, int *tile_len, int *tiles);
 
 void synthesis_signal_dev(voc_ctx *c, const double *mag, const double *inc, long long ldk, long long F, long long C,
-                          double *phase_io, double *y, long long y_stride, long long y_len, hipStream_t st)
+                          double *phase_io, double *y, long long y_stride, long long y_len, hipStream_t st,
+                          const long long *mag_rows = nullptr, long long F_mag = 0, const long long *inc_rows = nullptr,
+                          long long F_inc = 0)
 {
     if (C <= 0 || F <= 0) return;
     const bool fused = !c->bluestein && lds_bytes(c, true) <= kLdsLimit;
@@ -499,8 +502,8 @@ void synthesis_signal_dev(voc_ctx *c, const double *mag, const double *inc, long
         const long long chains = (C - unsplit) * c->K;
         LaunchTimer timer(c, KIND_CARRY, st);
         hipLaunchKernelGGL(voc::phase_carry_kernel<double>, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, c->params,
-                           inc + (size_t)unsplit * F * ldk, ldk, F, (const double *)(pin + unsplit * c->K), carry, tile_len, tiles,
-                           halo, C - unsplit);
+                           inc + (size_t)unsplit * (F_inc ? F_inc : F) * ldk, ldk, F, (const double *)(pin + unsplit * c->K), carry,
+                           tile_len, tiles, halo, C - unsplit, inc_rows, F_inc);
         HIPCHK(hipGetLastError());
     }
     voc::SynArgs s{};
@@ -518,6 +521,10 @@ void synthesis_signal_dev(voc_ctx *c, const double *mag, const double *inc, long
     s.tiles = tiles;
     s.halo = halo;
     s.unsplit = unsplit;
+    s.mag_rows = mag_rows;
+    s.inc_rows = inc_rows;
+    s.F_mag = F_mag;
+    s.F_inc = F_inc;
     if (fused) {
         if (!launch_synthesis_fast(c, s, C, true, st)) launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_OLA>(c, s, C, st);
     } else {
@@ -688,7 +695,8 @@ void roundtrip_dev(voc_ctx *c, const R *x, long long x_stride, long long len, lo
             LaunchTimer timer(c, KIND_CARRY, st);
             hipLaunchKernelGGL(voc::phase_carry_kernel<R>, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st,
                                params_of<R>(c), (const R *)(inc + (size_t)unsplit * F * r.ldk), r.ldk, F,
-                               (const R *)(pinS + unsplit * c->K), carry, r.syn_tile, r.syn_tiles, r.halo, G - unsplit);
+                               (const R *)(pinS + unsplit * c->K), carry, r.syn_tile, r.syn_tiles, r.halo, G - unsplit,
+                           (const long long *)nullptr, 0LL);
             HIPCHK(hipGetLastError());
         }
         voc::SynArgsT<R> s{};
@@ -1241,6 +1249,27 @@ VOC_EXPORT int32_t voc_synthesis_signal_dev(voc_ctx *c, const double *mag, const
     return guarded(c, [&]() -> int32_t {
         Locked lk(c);
         synthesis_signal_dev(c, mag, ph_inc, ldk, F, C, phase_io, y, y_stride, y_len, (hipStream_t)stream);
+        return VOC_OK;
+    });
+}
+
+VOC_EXPORT int32_t voc_synthesis_mapped_dev(voc_ctx *c, const double *mag, int64_t mag_frames, const int64_t *mag_rows,
+                                            const double *ph_inc, int64_t inc_frames, const int64_t *inc_rows, int64_t ldk,
+                                            int64_t F, int64_t C, double *phase_io, double *y, int64_t y_stride,
+                                            int64_t y_len, void *stream)
+{
+    if (!c || C < 0 || F < 0) return VOC_ERR_INVALID;
+    if (C == 0 || F == 0) return VOC_OK;
+    if (!mag || !ph_inc || !phase_io || !y) return VOC_ERR_INVALID;
+    if (ldk < c->K || y_len < (F - 1) * (int64_t)c->H + c->W || y_stride < y_len) return VOC_ERR_SIZE;
+    // an array without a map holds exactly the frames that are synthesised; a mapped one at least one row
+    if ((mag_rows ? mag_frames < 1 : mag_frames != F) || (inc_rows ? inc_frames < 1 : inc_frames != F)) return VOC_ERR_SIZE;
+    static_assert(sizeof(long long) == sizeof(int64_t), "row maps are passed through as long long");
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c);
+        synthesis_signal_dev(c, mag, ph_inc, ldk, F, C, phase_io, y, y_stride, y_len, (hipStream_t)stream,
+                             reinterpret_cast<const long long *>(mag_rows), mag_frames,
+                             reinterpret_cast<const long long *>(inc_rows), inc_frames);
         return VOC_OK;
     });
 }

@@ -218,6 +218,39 @@ class BoundFilter:
                 m3, i3 = np.ascontiguousarray(m3[:, src]), np.ascontiguousarray(i3[:, src])
         return (m3, i3) if multi else (m3[0], i3[0])
 
+    def apply_dev_lazy(self, mag, ph_inc):
+        """Like apply_dev, but a play_speed stage only composes a row map; an array is gathered
+        only when a later chain reads it (a chain that overwrites ph_inc without reading it, like
+        random_phase, gets a fresh array instead).  Returns (mag, mag_rows, ph_inc, inc_rows,
+        frames_out): maps are int64 device tensors or None, to be handed to
+        voc_synthesis_mapped_dev."""
+        import torch
+
+        st = C.c_void_p(torch.cuda.current_stream(mag.device).cuda_stream) if mag.is_cuda else None
+        mrows = irows = None
+        c, f, ldk = mag.shape
+        for kind, v in self.parts:
+            if kind == "speed":
+                src = torch.from_numpy(play_speed_map(self.par, v, f)).to(mag.device)
+                mrows = src if mrows is None else mrows[src]
+                irows = src if irows is None else irows[src]
+                f = src.numel()
+                continue
+            flags = (C.c_int32 * 4)()
+            self.par.lib.check(self.par.lib.dll.voc_filter_touches(v._h, flags))
+            load_mag, store_mag, load_inc, store_inc = (int(x) for x in flags)
+            if (load_mag or store_mag) and mrows is not None:
+                mag, mrows = mag.index_select(1, mrows), None
+            if irows is not None:
+                if load_inc:
+                    ph_inc, irows = ph_inc.index_select(1, irows), None
+                elif store_inc:
+                    ph_inc, irows = torch.empty((c, f, ldk), dtype=ph_inc.dtype, device=ph_inc.device), None
+            if f and (load_mag or store_mag or load_inc or store_inc):
+                self.par.lib.check(self.par.lib.dll.voc_filter_apply_dev(
+                    v._h, C.c_void_p(mag.data_ptr()), C.c_void_p(ph_inc.data_ptr()), ldk, f, c, st), self.par.handle)
+        return mag, mrows, ph_inc, irows, f
+
     def apply_dev(self, mag, ph_inc):
         """torch tensors (C, F, ldk) in device memory: per-frame chains run in place; a play_speed
         stage gathers into new tensors.  Returns the (mag, ph_inc) to hand to synthesis."""
