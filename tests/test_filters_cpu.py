@@ -287,5 +287,6 @@ def test_play_speed_then_filters_lazy_equals_eager(par, emu_lib):
         me, ie = b.apply_dev(mag.clone(), inc.clone())
         ml, mr, il, ir, fo = b.apply_dev_lazy(mag.clone(), inc.clone())
         assert (mr is not None) == lazy_mag and (ir is not None) == lazy_inc and fo == me.shape[1]
-        assert torch.equal(ml if mr is None else ml[:, mr], me)
-        assert torch.equal(il if ir is None else il[:, ir], ie)
+        k = par.K                                   # (the pad column of a fresh ph_inc is never written)
+        assert torch.equal((ml if mr is None else ml[:, mr])[..., :k], me[..., :k])
+        assert torch.equal((il if ir is None else il[:, ir])[..., :k], ie[..., :k])
