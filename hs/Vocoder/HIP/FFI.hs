@@ -112,3 +112,36 @@ foreign import ccall safe   "voc_stream_push" c_voc_stream_push
     :: Ptr VocStream -> Ptr Double -> Int64 -> Int64 -> Ptr Double -> Int64 -> Int64 -> Ptr Int64 -> IO Int32
 foreign import ccall safe   "voc_stream_flush" c_voc_stream_flush
     :: Ptr VocStream -> Ptr Double -> Int64 -> Int64 -> Ptr Int64 -> IO Int32
+
+-- * Device-resident entry points (pointers into GPU memory, a HIP stream as @Ptr ()@; for hosts
+--   that keep their buffers on the device through a HIP binding of their own).  They enqueue and
+--   return; the caller synchronises the stream.
+
+-- | x, x_stride, nframes, channels, phase_io, mag, ph_inc, ldk, volume_fix, stream
+foreign import ccall safe "voc_analysis_signal_dev" c_voc_analysis_signal_dev
+    :: Ptr VocCtx -> Ptr Double -> Int64 -> Int64 -> Int64 -> Ptr Double -> Ptr Double -> Ptr Double -> Int64 -> Int32
+    -> Ptr () -> IO Int32
+-- | mag, ph_inc, ldk, nframes, channels, phase_io, y, y_stride, y_len, stream
+foreign import ccall safe "voc_synthesis_signal_dev" c_voc_synthesis_signal_dev
+    :: Ptr VocCtx -> Ptr Double -> Ptr Double -> Int64 -> Int64 -> Int64 -> Ptr Double -> Ptr Double -> Int64 -> Int64
+    -> Ptr () -> IO Int32
+-- | mag, mag_frames, mag_rows, ph_inc, inc_frames, inc_rows, ldk, nframes, channels, phase_io, y, y_stride, y_len,
+--   stream: synthesis through the row maps of 'playSpeedMap' (no gathered copy of the STFT)
+foreign import ccall safe "voc_synthesis_mapped_dev" c_voc_synthesis_mapped_dev
+    :: Ptr VocCtx -> Ptr Double -> Int64 -> Ptr Int64 -> Ptr Double -> Int64 -> Ptr Int64 -> Int64 -> Int64 -> Int64
+    -> Ptr Double -> Ptr Double -> Int64 -> Int64 -> Ptr () -> IO Int32
+-- | ph_inc, ldk, nframes, channels, phase_io, stream
+foreign import ccall safe "voc_phase_advance_dev" c_voc_phase_advance_dev
+    :: Ptr VocCtx -> Ptr Double -> Int64 -> Int64 -> Int64 -> Ptr Double -> Ptr () -> IO Int32
+-- | mag, ph_inc, ldk, nframes, channels, stream
+foreign import ccall safe "voc_filter_apply_dev" c_voc_filter_apply_dev
+    :: Ptr VocFilter -> Ptr Double -> Ptr Double -> Int64 -> Int64 -> Int64 -> Ptr () -> IO Int32
+-- | flags4 <- {reads mag, writes mag, reads ph_inc, writes ph_inc}
+foreign import ccall unsafe "voc_filter_touches" c_voc_filter_touches :: Ptr VocFilter -> Ptr Int32 -> IO Int32
+-- | x, x_stride, length, channels, chunk, y, y_stride, ana_phase_io, syn_phase_io, leftover, leftover_stride,
+--   workspace, workspace_bytes, stream
+foreign import ccall safe "voc_roundtrip_dev" c_voc_roundtrip_dev
+    :: Ptr VocCtx -> Ptr Double -> Int64 -> Int64 -> Int64 -> Int64 -> Ptr Double -> Int64 -> Ptr Double -> Ptr Double
+    -> Ptr Double -> Int64 -> Ptr () -> Int64 -> Ptr () -> IO Int32
+foreign import ccall unsafe "voc_roundtrip_workspace_bytes" c_voc_roundtrip_workspace_bytes
+    :: Ptr VocCtx -> Int64 -> Int64 -> IO Int64
