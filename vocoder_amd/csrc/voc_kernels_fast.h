@@ -416,7 +416,9 @@ VOC_UNROLL(VOC_POLAR_UNROLL)
 // PAIRS (2(t + jT), 2(t + jT) + 1), j = 0..7, of the N-sample window -- one complex LDS element,
 // one 16-byte window load and one 16-byte store per pair -- and the partial sums shift by NHP
 // pairs per frame.  y rows must be 16-byte aligned.
-template <int LOG2M, bool OLA, int NHP, class R = double>
+// MAPPED: rows are looked up through a.mag_rows / a.inc_rows (a build of its own: the lookups cost
+// the unmapped path 1 % when they are decided at run time).
+template <int LOG2M, bool OLA, int NHP, class R = double, bool MAPPED = false>
 __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_fast_kernel(ParamsT<R> p, SynArgsT<R> a)
 {
     using C2 = cplx<R>;
@@ -452,7 +454,8 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
     // STFT row of frame f: (mag, ph_inc) of this thread's eight bins, plus DC / Nyquist for thread 0
     R mg[8], ic[8], mg0 = (R)0, mgm = (R)0, ic0 = (R)0, icm = (R)0;
     auto load_row = [&](long long f, int lt) {
-        const R *mrow = mag_row_of(a, c, f), *irow = inc_row_of(a, c, f);
+        const R *mrow = MAPPED ? mag_row_of(a, c, f) : a.mag + (c * a.F + f) * a.ldk;
+        const R *irow = MAPPED ? inc_row_of(a, c, f) : a.inc + (c * a.F + f) * a.ldk;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const unsigned pr = lt + m * T;

@@ -275,18 +275,22 @@ inline int fast_ola_nhp(const voc_ctx *c, const voc::SynArgsT<R> &a)
     return (nhp == 1 || nhp == 2 || nhp == 4 || nhp == 8) ? nhp : 0;
 }
 
-template <int L, bool OLA, class R>
+template <int L, bool OLA, class R, bool MAPPED = false>
 void launch_synthesis_fast_nh(voc_ctx *c, const voc::SynArgsT<R> &a, unsigned grid, int nhp, hipStream_t st)
 {
     const dim3 g(grid), b(voc::FastCfg<L>::T);
     const size_t lds = voc::FastCfg<L>::template lds_bytes<R>();
     switch (nhp) {
-    case 1: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 1, R>), g, b, lds, st, params_of<R>(c), a); break;
-    case 2: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 2, R>), g, b, lds, st, params_of<R>(c), a); break;
-    case 4: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 4, R>), g, b, lds, st, params_of<R>(c), a); break;
-    default: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 8, R>), g, b, lds, st, params_of<R>(c), a); break;
+    case 1: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 1, R, MAPPED>), g, b, lds, st, params_of<R>(c), a); break;
+    case 2: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 2, R, MAPPED>), g, b, lds, st, params_of<R>(c), a); break;
+    case 4: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 4, R, MAPPED>), g, b, lds, st, params_of<R>(c), a); break;
+    default: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 8, R, MAPPED>), g, b, lds, st, params_of<R>(c), a); break;
     }
 }
+
+// (the mapped build exists for double only; this keeps the float instantiation of the launcher well formed)
+inline const voc::SynArgsT<double> &as_double_args(const voc::SynArgsT<double> &a) { return a; }
+inline voc::SynArgsT<double> as_double_args(const voc::SynArgsT<float> &) { return voc::SynArgsT<double>{}; }
 
 // Specialised synthesis kernel (polar input): frames out, or overlap-add out when fast_ola_nhp() != 0.
 template <class R>
@@ -295,6 +299,8 @@ bool launch_synthesis_fast(voc_ctx *c, const voc::SynArgsT<R> &a, long long chan
     if (!fast_sizes(c)) return false;
     const int nh = ola ? fast_ola_nhp(c, a) : 8;
     if (ola && nh == 0) return false;
+    const bool mapped = a.mag_rows || a.inc_rows;
+    if (mapped && !(ola && std::is_same<R, double>::value)) return false;  // the generic kernel reads through maps too
     const long long grid = a.unsplit + (channels - a.unsplit) * a.tiles;
     if (grid <= 0) return true;
     if (grid > 0x7fffffffLL) throw HipFail{hipErrorInvalidValue, "synthesis grid too large"};
@@ -302,7 +308,8 @@ bool launch_synthesis_fast(voc_ctx *c, const voc::SynArgsT<R> &a, long long chan
     switch (c->log2m) {
 #define X(L)                                                                          \
     case L:                                                                           \
-        if (ola) launch_synthesis_fast_nh<L, true, R>(c, a, (unsigned)grid, nh, st);     \
+        if (mapped) launch_synthesis_fast_nh<L, true, double, true>(c, as_double_args(a), (unsigned)grid, nh, st); \
+        else if (ola) launch_synthesis_fast_nh<L, true, R>(c, a, (unsigned)grid, nh, st);     \
         else hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, false, 8, R>), dim3((unsigned)grid), \
                                 dim3(voc::FastCfg<L>::T), voc::FastCfg<L>::template lds_bytes<R>(), st, params_of<R>(c), a); \
         break;
