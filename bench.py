@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--precision", choices=("f64", "f32"), default="f64",
                     help="f32: the single-precision variant (not the metric; reported with dtype f32)")
     ap.add_argument("--cpu-streams", type=int, default=24, help="streams of the workload the CPU oracle is timed on")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (gloo: rehearsal of the multi-rank path without RCCL)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,10 +98,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     from vocoder_amd import distributed as D
-    D.init("nccl", dev)
+    D.init(args.backend, dev)
+    red_dev = dev if args.backend == "nccl" else "cpu"   # where the one reduced scalar lives
 
     from vocoder_amd import vocoder as V, conduit as Cd, window as Wn
     win = Wn.hann_window(N_FFT)
@@ -136,7 +141,7 @@ def main():
     ms = (np.zeros(4), np.zeros(4, dtype=np.int64))
     par.lib.check(par.lib.dll.voc_profile_read(par.handle, ms[0].ctypes.data, ms[1].ctypes.data))
     par.lib.check(par.lib.dll.voc_profile_enable(par.handle, 0))
-    dt = D.max_over_ranks(dt, dev)
+    dt = D.max_over_ranks(dt, red_dev)
 
     if rank == 0:
         value = frames * world * args.steps / dt
