@@ -180,6 +180,15 @@ def add_incoming_tail(y_local, tail):
     return y_local
 
 
+def _exchange(ops):
+    """The neighbour exchange as one batch (under RCCL the send to the next rank and the receive
+    from the previous one are grouped, so neither waits for the other to be matched first)."""
+    import torch.distributed as dist
+    if ops:
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+
+
 def process(par, x_seg, length: int, chunk: int | None = None, ana_phase=None, syn_phase=None, group=None):
     """Round trip of one time segment under torch.distributed (identity filter).
 
@@ -202,19 +211,18 @@ def process(par, x_seg, length: int, chunk: int | None = None, ana_phase=None, s
         totals = [total]
     y, sph = synthesise(par, sp, mag, inc, start_phase(totals, rank, syn_phase))
     if world > 1:
-        reqs = []
+        ops = []
         tail_in = None
         if sp.tail:
             send = y[:, sp.out_hi - sp.out_lo:].contiguous()
-            reqs.append(dist.isend(send, dist.get_global_rank(group, rank + 1) if group else rank + 1, group=group))
+            ops.append(dist.P2POp(dist.isend, send, dist.get_global_rank(group, rank + 1) if group else rank + 1, group))
         if rank > 0:
             prev = plan(par, length, world, rank - 1, chunk)
             if prev.tail:
                 tail_in = torch.empty((y.shape[0], prev.tail), dtype=torch.float64, device=y.device)
-                reqs.append(dist.irecv(tail_in, dist.get_global_rank(group, rank - 1) if group else rank - 1,
-                                       group=group))
-        for r in reqs:
-            r.wait()
+                ops.append(dist.P2POp(dist.irecv, tail_in, dist.get_global_rank(group, rank - 1) if group else rank - 1,
+                                      group))
+        _exchange(ops)
         if tail_in is not None:
             add_incoming_tail(y, tail_in)
         last = dist.get_global_rank(group, world - 1) if group else world - 1
@@ -331,16 +339,15 @@ def process_pieces(par, source, length: int, piece_frames: int, sink=None, filt=
         del mag, inc, y
 
     if world > 1:
-        reqs = []
+        ops = []
         if sp.tail:
-            reqs.append(dist.isend(tail.contiguous(), dist.get_global_rank(group, rank + 1) if group else rank + 1,
-                                   group=group))
+            ops.append(dist.P2POp(dist.isend, tail.contiguous(), dist.get_global_rank(group, rank + 1) if group else rank + 1,
+                                  group))
         tail_in = None
         if prev_tail:
             tail_in = torch.empty_like(held)
-            reqs.append(dist.irecv(tail_in, dist.get_global_rank(group, rank - 1) if group else rank - 1, group=group))
-        for r in reqs:
-            r.wait()
+            ops.append(dist.P2POp(dist.irecv, tail_in, dist.get_global_rank(group, rank - 1) if group else rank - 1, group))
+        _exchange(ops)
         if tail_in is not None:
             held = tail_in + held
             if collected is not None:
