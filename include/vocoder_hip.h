@@ -104,6 +104,11 @@ int32_t voc_synthesis_step(voc_ctx *ctx, const double *ph, const double *mag, co
                            double *spec, int64_t batch);
 int32_t voc_add_frames(voc_ctx *ctx, const double *mag1, const double *inc1, const double *mag2, const double *inc2,
                        double *mag_out, double *inc_out, int64_t batch);
+/* addFrames on device arrays: element-wise over `count` doubles of six arrays with one common
+ * layout (rows with any pitch included); an output may be one of the inputs.  With two filter
+ * chains run on copies of an STFT this is addFilters (Filter.hs:58-59). */
+int32_t voc_add_frames_dev(voc_ctx *ctx, const double *mag1, const double *inc1, const double *mag2, const double *inc2,
+                           double *mag_out, double *inc_out, int64_t count, void *stream);
 
 /* ---- stage level (the batched hot path) -----------------------------------------------
  * voc_analysis_stage  replaces analysisStage par ph frames           Vocoder.hs:149-150
@@ -243,7 +248,7 @@ int32_t voc_synthesis_mapped_dev(voc_ctx *ctx, const double *mag, int64_t mag_fr
  * counter (bin, row, position in the chain), row = channel * nframes + frame.
  * voc_filter_apply[_dev] runs the chain in place on mag / ph_inc ([C][F][K] host arrays, or
  * device arrays with row pitch ldk).  At most 12 operations per chain (VOC_ERR_SIZE beyond).
- * addFilters (Filter.hs:58-59) is not provided: run two chains on copies and voc_add_frames.
+ * addFilters (Filter.hs:58-59): run the two chains on copies and add them with voc_add_frames[_dev].
  */
 typedef struct voc_filter voc_filter;
 enum {

@@ -290,3 +290,37 @@ def test_play_speed_then_filters_lazy_equals_eager(par, emu_lib):
         k = par.K                                   # (the pad column of a fresh ph_inc is never written)
         assert torch.equal((ml if mr is None else ml[:, mr])[..., :k], me[..., :k])
         assert torch.equal((il if ir is None else il[:, ir])[..., :k], ie[..., :k])
+
+
+def test_add_filters_matches_oracle(par, orc):
+    """addFilters f1 f2 (Filter.hs:58-59): both chains on the same frames, outputs added as
+    complex numbers; host arrays, device arrays and inside a longer description."""
+    import torch
+    from vocoder_amd import filter as Fl
+    step = 375.0
+    mag, inc = _stft(par, c=2, f=4, seed=11)
+    low = [("lowpass_butterworth", 2.0, 3000.0)]
+    high = [("highpass_brickwall", 6000.0), ("amplify", 0.5)]
+    descr = Fl.amplify(2.0) >> Fl.add_filters(_describe(low), _describe(high)) >> Fl.amplify(0.25)
+    b = descr.bind(par, step)
+    assert not b.changes_frame_count and b.frames_out(4) == 4
+
+    m0, i0 = orc.apply_filter(step, [("amplify", 2.0)], mag, inc)
+    (ma, ia), (mb, ib) = orc.apply_filter(step, low, m0, i0), orc.apply_filter(step, high, m0, i0)
+    ms, is_ = np.empty_like(ma), np.empty_like(ia)
+    for c in range(2):
+        for f in range(4):
+            ms[c, f], is_[c, f] = orc.add_frames(ma[c, f], ia[c, f], mb[c, f], ib[c, f])
+    me, ie = orc.apply_filter(step, [("amplify", 0.25)], ms, is_)
+
+    m, i = b.apply(mag, inc)
+    assert np.allclose(m, me, rtol=1e-12, atol=1e-15)
+    assert np.abs(np.angle(np.exp(1j * (i - ie)))).max() <= 1e-9
+    ldk = (par.K + 1) & ~1
+    pad = lambda a: torch.nn.functional.pad(torch.from_numpy(a), (0, ldk - par.K)).contiguous()
+    md, idv = b.apply_dev(pad(mag), pad(inc))
+    assert np.array_equal(md[..., :par.K].numpy(), m) and np.array_equal(idv[..., :par.K].numpy(), i)
+    ml, mr, il, ir, fo = b.apply_dev_lazy(pad(mag), pad(inc))
+    assert mr is None and ir is None and fo == 4 and torch.equal(ml[..., :par.K], md[..., :par.K])
+    with pytest.raises(ValueError):
+        Fl.add_filters(Fl.play_speed(2), Fl.id_filter()).bind(par, step).frames_out(4)

@@ -157,3 +157,27 @@ def test_mapped_synthesis_equals_gather_then_synthesis(gpu_lib, monkeypatch, n, 
     specialised, the generic and the frames-in-memory synthesis kernels, whole and tiled."""
     from test_filters_cpu import _mapped_vs_gathered
     _mapped_vs_gathered(gpu_lib, n, hop, c, f_in, coeff, monkeypatch, tile, None, device="cuda")
+
+
+def test_add_filters_on_device(gpu_lib, orc):
+    """addFilters (Filter.hs:58-59) on device arrays against the oracle's chains and addFrames."""
+    import torch
+    from vocoder_amd import vocoder as V, filter as Fl
+    par = V.VocoderParams(4096, 1024, _hann(4096), lib=gpu_lib)
+    step = 48000.0 / 4096
+    rng = np.random.default_rng(21)
+    c, f = 2, 5
+    ldk = (par.K + 1) & ~1
+    mag, inc = rng.uniform(0, 1, (c, f, ldk)), rng.uniform(-1, 1, (c, f, ldk))
+    low, high = [("lowpass_brickwall", 1000.0)], [("highpass_butterworth", 2.0, 4000.0), ("amplify", 0.5)]
+    b = Fl.add_filters(_build(low), _build(high)).bind(par, step)
+    md, idv = b.apply_dev(torch.from_numpy(mag).cuda(), torch.from_numpy(inc).cuda())
+    md, idv = md.cpu().numpy()[..., :par.K], idv.cpu().numpy()[..., :par.K]
+    m0, i0 = mag[..., :par.K], inc[..., :par.K]
+    (ma, ia), (mb, ib) = orc.apply_filter(step, low, m0, i0), orc.apply_filter(step, high, m0, i0)
+    for ch in range(c):
+        for fr in range(f):
+            me, ie = orc.add_frames(ma[ch, fr], ia[ch, fr], mb[ch, fr], ib[ch, fr])
+            assert np.allclose(md[ch, fr], me, rtol=1e-12, atol=1e-15)
+            live = me > 1e-9
+            assert np.abs(np.angle(np.exp(1j * (idv[ch, fr] - ie))))[live].max() <= 1e-9

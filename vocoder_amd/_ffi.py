@@ -34,6 +34,7 @@ SIGNATURES = {
     "voc_analysis_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64]),
     "voc_synthesis_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64]),
     "voc_add_frames": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64]),
+    "voc_add_frames_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "voc_analysis_stage": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64]),
     "voc_synthesis_stage": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64]),
     "voc_analysis_stage_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),

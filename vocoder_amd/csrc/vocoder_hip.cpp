@@ -1089,6 +1089,20 @@ VOC_EXPORT int32_t voc_add_frames(voc_ctx *c, const double *mag1, const double *
     });
 }
 
+VOC_EXPORT int32_t voc_add_frames_dev(voc_ctx *c, const double *mag1, const double *inc1, const double *mag2,
+                                      const double *inc2, double *mag_out, double *inc_out, int64_t count, void *stream)
+{
+    if (!c || count < 0 || (count > 0 && (!mag1 || !inc1 || !mag2 || !inc2 || !mag_out || !inc_out))) return VOC_ERR_INVALID;
+    if (count == 0) return VOC_OK;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c);
+        hipLaunchKernelGGL(voc::add_frames_kernel, dim3(ew_grid((long long)count)), dim3(256), 0, (hipStream_t)stream, mag1,
+                           inc1, mag2, inc2, mag_out, inc_out, (long long)count);
+        HIPCHK(hipGetLastError());
+        return VOC_OK;
+    });
+}
+
 // ---- stage level ------------------------------------------------------------------------------------------
 
 VOC_EXPORT int32_t voc_analysis_stage_dev(voc_ctx *c, double *phase_io, const double *frames, double *mag,

@@ -18,7 +18,7 @@ import numpy as np
 from .vocoder import VocoderParams, _f64, _p
 
 __all__ = [
-    "Filter", "id_filter", "compose_filters", "amplify", "linear_amplitude_filter", "lowpass_brickwall",
+    "Filter", "id_filter", "compose_filters", "add_filters", "amplify", "linear_amplitude_filter", "lowpass_brickwall",
     "highpass_brickwall", "bandpass_brickwall", "bandstop_brickwall", "lowpass_butterworth",
     "highpass_butterworth", "bandpass_butterworth", "bandstop_butterworth", "pitch_shift_interpolate",
     "convolution_filter", "envelope_filter", "random_phase_filter", "play_speed", "BoundFilter",
@@ -54,6 +54,13 @@ def id_filter() -> Filter:
 def compose_filters(f1: Filter, f2: Filter) -> Filter:
     """composeFilters f1 f2: f1 first, then f2 (Filter.hs:54-55)."""
     return Filter(f1.stages + f2.stages)
+
+
+def add_filters(f1: Filter, f2: Filter) -> Filter:
+    """addFilters f1 f2 (Filter.hs:58-59): both filters see the same frame; their outputs are
+    added as complex numbers (addFrames, Vocoder.hs:220-222).  Both must produce the same number
+    of frames."""
+    return Filter((("add", (f1, f2)),))
 
 
 def _one(name, *params):
@@ -181,9 +188,14 @@ class BoundFilter:
         for st in filt.stages:
             if st[0] in ("convolution", "envelope"):
                 self.zero_inc = True
-            elif st[0] == "random_phase":
+            elif st[0] in ("random_phase", "add"):      # addFrames returns phases as increments
                 self.zero_inc = False
-            if st[0] == "play_speed":
+            if st[0] == "add":
+                if run:
+                    self._add_chains(run)
+                    run = []
+                self.parts.append(("add", tuple(BoundFilter(par, freq_step, f) for f in st[1])))
+            elif st[0] == "play_speed":
                 if run:
                     self._add_chains(run)
                     run = []
@@ -197,11 +209,22 @@ class BoundFilter:
         for i in range(0, len(stages), limit):
             self.parts.append(("chain", _Chain(self.par, self.step, stages[i:i + limit])))
 
+    @property
+    def changes_frame_count(self) -> bool:
+        """True when a play_speed stage occurs anywhere in the description."""
+        return any(kind == "speed" or (kind == "add" and any(b.changes_frame_count for b in v))
+                   for kind, v in self.parts)
+
     def frames_out(self, nframes_in: int) -> int:
         f = nframes_in
         for kind, v in self.parts:
             if kind == "speed":
                 f = play_speed_frames(self.par, v, f)
+            elif kind == "add":
+                fa, fb = (b.frames_out(f) for b in v)
+                if fa != fb:
+                    raise ValueError(f"add_filters: the two filters produce {fa} and {fb} frames")
+                f = fa
         return f
 
     def apply(self, mag, ph_inc):
@@ -213,6 +236,12 @@ class BoundFilter:
             if kind == "chain":
                 c, f, _ = m3.shape
                 self.par.lib.check(self.par.lib.dll.voc_filter_apply(v._h, _p(m3), _p(i3), f, c), self.par.handle)
+            elif kind == "add":
+                self.frames_out(m3.shape[1])
+                (ma, ia), (mb, ib) = (b.apply(m3, i3) for b in v)
+                m3, i3 = np.empty_like(ma), np.empty_like(ia)
+                self.par._call("voc_add_frames", _p(ma), _p(ia), _p(mb), _p(ib), _p(m3), _p(i3),
+                               ma.shape[0] * ma.shape[1])
             else:
                 src = play_speed_map(self.par, v, m3.shape[1])
                 m3, i3 = np.ascontiguousarray(m3[:, src]), np.ascontiguousarray(i3[:, src])
@@ -236,6 +265,14 @@ class BoundFilter:
                 irows = src if irows is None else irows[src]
                 f = src.numel()
                 continue
+            if kind == "add":      # both branches read everything: gather what is still mapped, then as in apply_dev
+                if mrows is not None:
+                    mag, mrows = mag.index_select(1, mrows), None
+                if irows is not None:
+                    ph_inc, irows = ph_inc.index_select(1, irows), None
+                mag, ph_inc = self._apply_add(v, mag, ph_inc, st)
+                f = mag.shape[1]
+                continue
             flags = (C.c_int32 * 4)()
             self.par.lib.check(self.par.lib.dll.voc_filter_touches(v._h, flags))
             load_mag, store_mag, load_inc, store_inc = (int(x) for x in flags)
@@ -251,6 +288,16 @@ class BoundFilter:
                     v._h, C.c_void_p(mag.data_ptr()), C.c_void_p(ph_inc.data_ptr()), ldk, f, c, st), self.par.handle)
         return mag, mrows, ph_inc, irows, f
 
+    def _apply_add(self, pair, mag, ph_inc, st):
+        self.frames_out(mag.shape[1])
+        ma, ia = pair[0].apply_dev(mag.clone(), ph_inc.clone())
+        mag, ph_inc = pair[1].apply_dev(mag, ph_inc)
+        if mag.numel():
+            self.par._call("voc_add_frames_dev", C.c_void_p(ma.data_ptr()), C.c_void_p(ia.data_ptr()),
+                           C.c_void_p(mag.data_ptr()), C.c_void_p(ph_inc.data_ptr()), C.c_void_p(mag.data_ptr()),
+                           C.c_void_p(ph_inc.data_ptr()), mag.numel(), st)
+        return mag, ph_inc
+
     def apply_dev(self, mag, ph_inc):
         """torch tensors (C, F, ldk) in device memory: per-frame chains run in place; a play_speed
         stage gathers into new tensors.  Returns the (mag, ph_inc) to hand to synthesis."""
@@ -262,6 +309,8 @@ class BoundFilter:
             if kind == "chain":
                 self.par.lib.check(self.par.lib.dll.voc_filter_apply_dev(
                     v._h, C.c_void_p(mag.data_ptr()), C.c_void_p(ph_inc.data_ptr()), ldk, f, c, st), self.par.handle)
+            elif kind == "add":
+                mag, ph_inc = self._apply_add(v, mag, ph_inc, st)
             else:
                 src = torch.from_numpy(play_speed_map(self.par, v, f)).to(mag.device)
                 fo = src.numel()

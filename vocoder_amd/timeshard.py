@@ -238,7 +238,7 @@ def _zero_increments(filt) -> bool:
 def _filtered(filt, mag, inc):
     if filt is None:
         return mag, inc
-    if any(kind == "speed" for kind, _ in filt.parts):
+    if filt.changes_frame_count:
         raise ValueError("play_speed changes the number of frames: it cannot run on a time-sharded signal")
     return filt.apply_dev(mag, inc)
 
