@@ -19,7 +19,7 @@ vocoder-conduit and vocoder-dunai need no source change: they only use the names
 module Vocoder.HIP
     ( VocoderParams, vocoderParams, vocFrameLength, vocInputFrameLength, vocFreqFrameLength
     , vocHopSize, vocWindow, analysisStage, analysisBlock, synthesisStage, synthesisBlock
-    , zeroPhase, volumeCoeff, processChannels
+    , zeroPhase, volumeCoeff, addFrames, processChannels
     , Moduli, Phase, PhaseInc, Frame, Window, STFTFrame
     , vocCtx, check   -- for the sibling modules Vocoder.HIP.Filter
     ) where
@@ -152,3 +152,16 @@ processChannels par chunk xs (aphs, sphs) = unsafePerformIO $ do
         sv <- V.unsafeFreeze sm
         let rows n v = [V.slice (i * n) n v | i <- [0 .. c - 1]]
         return (rows ol yv, rows keep lv, (rows k av, rows k sv))
+
+-- | Adds STFT frames (Vocoder.hs:220-222): polar to complex, sum, complex to polar, on the device.
+addFrames :: VocoderParams -> STFTFrame -> STFTFrame -> STFTFrame
+addFrames par (m1, i1) (m2, i2) = unsafePerformIO $ do
+    let k = vocFreqFrameLength par
+    when (any ((/= k) . V.length) [m1, i1, m2, i2]) $ error "addFrames: frame length mismatch"
+    mo <- MV.new k
+    io <- MV.new k
+    withForeignPtr (vocCtx par) $ \ctx ->
+        V.unsafeWith m1 $ \pm1 -> V.unsafeWith i1 $ \pi1 -> V.unsafeWith m2 $ \pm2 -> V.unsafeWith i2 $ \pi2 ->
+            MV.unsafeWith mo $ \pmo -> MV.unsafeWith io $ \pio ->
+                check "addFrames" $ c_voc_add_frames ctx pm1 pi1 pm2 pi2 pmo pio 1
+    (,) <$> V.unsafeFreeze mo <*> V.unsafeFreeze io

@@ -13,7 +13,7 @@ module Vocoder.HIP.Filter
     , lowpassBrickwall, highpassBrickwall, bandpassBrickwall, bandstopBrickwall
     , lowpassButterworth, highpassButterworth, bandpassButterworth, bandstopButterworth
     , pitchShiftInterpolate, convolutionFilter, envelopeFilter, randomPhaseFilter
-    , applyFilter, playSpeedMap
+    , applyFilter, applyAddFilters, playSpeedMap
     ) where
 
 import Control.Monad
@@ -101,6 +101,13 @@ applyFilter par step (FilterDesc stages) frs = unsafePerformIO $ do
     let slice v i = V.slice (i * k) k v
         (_, out) = mapAccumL (\i _ -> (i + 1 :: Int, (slice magv i, slice incv i))) 0 frs
     return out
+
+-- | addFilters f1 f2 (Filter.hs:58-59) on a container of frames: both chains see the same
+--   frames, their outputs are added frame by frame with 'addFrames'.
+applyAddFilters :: Traversable t => VocoderParams -> FreqStep -> FilterDesc -> FilterDesc -> t STFTFrame -> t STFTFrame
+applyAddFilters par step f1 f2 frs = snd (mapAccumL pick (toList (applyFilter par step f2 frs)) (applyFilter par step f1 frs))
+    where pick (b : bs) a = (bs, addFrames par a b)
+          pick [] _ = error "applyAddFilters: containers of different shape"
 
 type FreqStep = Double
 
