@@ -359,9 +359,23 @@ VOC_DEV double hs_phase(double x, double y)
 // 1), then the classical degree-13 / degree-14 kernels on [-pi/4, pi/4].  Accurate to about an ulp
 // for |x| < 2^50 (a phase that large has a resolution of 0.25 rad; beyond it, and for inf / nan,
 // the result is NaN).
+//
+// LEAN gives the same bits with fewer instructions and no branch: the out-of-range NaN is made by
+// replacing the high word alone (the division of the plain form is compiled as a branch around it,
+// once per bin), and the quadrant signs are bit 1 of q (of q + 1) moved onto the sign bit instead of
+// two negate-and-select pairs.  Without the branches the bins of a loop body become one scheduling
+// region; where registers are scarce that region is scheduled worse than the separate ones, so the
+// caller chooses (the specialised synthesis kernel: lean from N = 2048 up).
+template <bool LEAN = false>
 VOC_DEV void fast_sincos(double x, double *sn, double *cs)
 {
-    x = (fabs(x) < 0x1p50) ? x : (x - x) / (x - x);
+    if (LEAN) {
+        const unsigned long long xb = __builtin_bit_cast(unsigned long long, x);
+        const unsigned hi = (fabs(x) < 0x1p50) ? (unsigned)(xb >> 32) : 0x7ff80000u;
+        x = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (xb & 0xffffffffull));
+    } else {
+        x = (fabs(x) < 0x1p50) ? x : (x - x) / (x - x);
+    }
     const double big = 0x1.8p52;
     const double tn = fma(x, 0.63661977236758138, big);
     const double n = tn - big;
@@ -385,8 +399,15 @@ VOC_DEV void fast_sincos(double x, double *sn, double *cs)
     const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
     const double s1 = (q & 1u) ? c : s;
     const double c1 = (q & 1u) ? s : c;
-    *sn = (q & 2u) ? -s1 : s1;
-    *cs = ((q + 1u) & 2u) ? -c1 : c1;
+    if (LEAN) {  // quadrants 2, 3 negate the sine, 1, 2 the cosine
+        const unsigned long long fs = (unsigned long long)((q << 30) & 0x80000000u) << 32;
+        const unsigned long long fc = (unsigned long long)(((q + 1u) << 30) & 0x80000000u) << 32;
+        *sn = __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, s1) ^ fs);
+        *cs = __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, c1) ^ fc);
+    } else {
+        *sn = (q & 2u) ? -s1 : s1;
+        *cs = ((q + 1u) & 2u) ? -c1 : c1;
+    }
 }
 
 // wrap e = (e + pi) `mod'` (2 pi) - pi with mod' n d = n - floor(n/d) * d and the floor taken
@@ -460,6 +481,7 @@ VOC_DEV void hs_polar(float x, float y, float &mag, float &ph)
 
 // sin and cos of a phase of moderate size (the float variant keeps its phases wrapped): Cody-Waite
 // reduction by pi/2 in two fma steps, minimax kernels on [-pi/4, pi/4] (errors 1.2e-8 / 8e-10).
+template <bool LEAN = false>
 VOC_DEV void fast_sincos(float x, float *sn, float *cs)
 {
     const float n = rintf(x * 0.636619772f);
@@ -555,13 +577,13 @@ VOC_DEV double phase_step(double ph, double t) { return ph + t; }
 VOC_DEV float phase_step(float ph, float t) { return (float)hs_wrap((double)ph + (double)t); }
 
 // synthesisStep for one bin (Vocoder.hs:186-190): the phase step, then mkPolar.
-template <class R>
+template <class R, bool LEAN = false>
 VOC_DEV cplx<R> synthesize_bin(const ParamsT<R> &p, R mag, R inc, R &ph)
 {
     const R t = inc * p.hop_d;
     ph = phase_step(ph, t);
     R s, c;
-    fast_sincos(ph, &s, &c);
+    fast_sincos<LEAN>(ph, &s, &c);
     return mk2(mag * c, mag * s);
 }
 

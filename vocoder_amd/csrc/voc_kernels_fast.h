@@ -24,6 +24,10 @@
 #define VOC_WS_PREFETCH 0  // fetch the window with the next frame's samples (aligned case)
 #endif
 
+#ifndef VOC_SYN_ROW_PREFETCH
+#define VOC_SYN_ROW_PREFETCH 2  // synthesis, next frame's STFT row loaded during this frame's transform: 0 never, 1 always, 2 by size
+#endif
+
 #ifndef VOC_SYN_FENCE
 #define VOC_SYN_FENCE 1
 #endif
@@ -474,18 +478,25 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
         }
     };
 
-    load_row(fs, tid);
+    // The next frame's row can be requested during this frame's transform, at the price of its 36
+    // registers staying live across the transform.  Measured (MI355X, fp64): without it the kernel
+    // needs 133 instead of 166 registers and runs 5-11 % faster at N >= 2048; the one-wave workgroups
+    // of N = 1024 are 4 % faster with it.
+    constexpr bool ROW_PF = VOC_SYN_ROW_PREFETCH == 1 || (VOC_SYN_ROW_PREFETCH == 2 && LOG2M <= 9);
+    constexpr bool LEAN = !ROW_PF;  // the branch-free sine / cosine pays only with the registers the prefetch took
+    if (ROW_PF) load_row(fs, tid);
     for (long long f = fs; f < f1; ++f) {
         const long long row = c * a.F + f;
         const int lt = opaque_int(tid);  // keeps this frame's index arithmetic inside the loop
+        if (!ROW_PF) load_row(f, lt);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const unsigned pr = lt + m * T;
             const unsigned pe = pr == 0 ? M / 2 : pr;
             const unsigned q = M - pe;
             R pa = php[pe], pb = php[q];
-            const C2 A = synthesize_bin(p, mg[2 * m], ic[2 * m], pa);
-            const C2 B = synthesize_bin(p, mg[2 * m + 1], ic[2 * m + 1], pb);
+            const C2 A = synthesize_bin<R, LEAN>(p, mg[2 * m], ic[2 * m], pa);
+            const C2 B = synthesize_bin<R, LEAN>(p, mg[2 * m + 1], ic[2 * m + 1], pb);
             php[pe] = pa;
             php[q] = pb;
             C2 Za, Zb;
@@ -509,7 +520,7 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
         load8<LOG2M>(lds, lt, v);
         dft<8>(v);
         fft_after_first<LOG2M>(lds, tw, lt, v, [&]() {
-            if (f + 1 < f1) load_row(f + 1, lt);
+            if (ROW_PF && f + 1 < f1) load_row(f + 1, lt);
         });
         // lds[pad(m)] = swapped z[m]: v[2m] = z.y / N, v[2m+1] = z.x / N.  frame[i] = w[i] * v[(i + off + N/2) mod N]
         const bool emit = f >= f0;
