@@ -24,6 +24,10 @@
 #define VOC_WS_PREFETCH 0  // fetch the window with the next frame's samples (aligned case)
 #endif
 
+#ifndef VOC_SYN_PHASE_REGS
+#define VOC_SYN_PHASE_REGS 1  // synthesis: accumulated phases in registers instead of LDS where the row prefetch is off
+#endif
+
 #ifndef VOC_SYN_ROW_PREFETCH
 #define VOC_SYN_ROW_PREFETCH 2  // synthesis, next frame's STFT row loaded during this frame's transform: 0 never, 1 always, 2 by size
 #endif
@@ -443,11 +447,34 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
     const long long halo = OLA ? ((long long)a.halo < f0 ? (long long)a.halo : f0) : 0;
     const long long fs = f0 - halo;
 
-    {
+    // The next frame's row can be requested during this frame's transform, at the price of its 36
+    // registers staying live across the transform.  Measured (MI355X, fp64): without it the kernel
+    // needs 133 instead of 166 registers and runs 5-11 % faster at N >= 2048; the one-wave workgroups
+    // of N = 1024 are 4 % faster with it.
+    constexpr bool ROW_PF = VOC_SYN_ROW_PREFETCH == 1 || (VOC_SYN_ROW_PREFETCH == 2 && LOG2M <= 9);
+    constexpr bool LEAN = !ROW_PF;  // the branch-free sine / cosine pays only with the registers the prefetch took
+    // ... and so does keeping the accumulated phases of this thread's eight bins (and of DC / Nyquist
+    // in thread 0) in registers instead of LDS: 4 % faster at N = 4096, 29 % slower at N = 1024.
+    constexpr bool PHASE_REGS = VOC_SYN_PHASE_REGS && !ROW_PF;
+    R phr[8] = {}, ph0 = (R)0, phm = (R)0;
+    if constexpr (PHASE_REGS) {
+        const R *pi = (tile == 0) ? a.phase_in + c * p.K : a.carry + ((c - a.unsplit) * a.tiles + tile) * p.K;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const unsigned pr = tid + m * T;
+            const unsigned pe = pr == 0 ? M / 2 : pr;
+            phr[2 * m] = pi[pe];
+            phr[2 * m + 1] = pi[M - pe];
+        }
+        if (tid == 0) {
+            ph0 = pi[0];
+            phm = pi[M];
+        }
+    } else {
         const R *pi = (tile == 0) ? a.phase_in + c * p.K : a.carry + ((c - a.unsplit) * a.tiles + tile) * p.K;
         for (int k = tid; k < p.K; k += T) php[k] = pi[k];
+        __syncthreads();
     }
-    __syncthreads();
 
     FastTw<LOG2M, C2> tw;  // frame-invariant twiddle bases of this thread
     fast_tw_init<LOG2M>(p, tid, tw);
@@ -478,12 +505,6 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
         }
     };
 
-    // The next frame's row can be requested during this frame's transform, at the price of its 36
-    // registers staying live across the transform.  Measured (MI355X, fp64): without it the kernel
-    // needs 133 instead of 166 registers and runs 5-11 % faster at N >= 2048; the one-wave workgroups
-    // of N = 1024 are 4 % faster with it.
-    constexpr bool ROW_PF = VOC_SYN_ROW_PREFETCH == 1 || (VOC_SYN_ROW_PREFETCH == 2 && LOG2M <= 9);
-    constexpr bool LEAN = !ROW_PF;  // the branch-free sine / cosine pays only with the registers the prefetch took
     if (ROW_PF) load_row(fs, tid);
     for (long long f = fs; f < f1; ++f) {
         const long long row = c * a.F + f;
@@ -494,11 +515,17 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
             const unsigned pr = lt + m * T;
             const unsigned pe = pr == 0 ? M / 2 : pr;
             const unsigned q = M - pe;
-            R pa = php[pe], pb = php[q];
-            const C2 A = synthesize_bin<R, LEAN>(p, mg[2 * m], ic[2 * m], pa);
-            const C2 B = synthesize_bin<R, LEAN>(p, mg[2 * m + 1], ic[2 * m + 1], pb);
-            php[pe] = pa;
-            php[q] = pb;
+            C2 A, B;
+            if constexpr (PHASE_REGS) {
+                A = synthesize_bin<R, LEAN>(p, mg[2 * m], ic[2 * m], phr[2 * m]);
+                B = synthesize_bin<R, LEAN>(p, mg[2 * m + 1], ic[2 * m + 1], phr[2 * m + 1]);
+            } else {
+                R pa = php[pe], pb = php[q];
+                A = synthesize_bin<R, LEAN>(p, mg[2 * m], ic[2 * m], pa);
+                B = synthesize_bin<R, LEAN>(p, mg[2 * m + 1], ic[2 * m + 1], pb);
+                php[pe] = pa;
+                php[q] = pb;
+            }
             C2 Za, Zb;
             merge_pair(A, B, split_tw(tw.s, m, pr == 0), Za, Zb);
             lds[lds_pad(pe)] = Za;
@@ -508,11 +535,16 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
 #endif
         }
         if (tid == 0) {  // DC and Nyquist: only the real parts enter the C2R transform
-            R p0 = php[0], pm = php[M];
-            const C2 A = synthesize_bin(p, mg0, ic0, p0);
-            const C2 B = synthesize_bin(p, mgm, icm, pm);
-            php[0] = p0;
-            php[M] = pm;
+            if constexpr (!PHASE_REGS) {
+                ph0 = php[0];
+                phm = php[M];
+            }
+            const C2 A = synthesize_bin(p, mg0, ic0, ph0);
+            const C2 B = synthesize_bin(p, mgm, icm, phm);
+            if constexpr (!PHASE_REGS) {
+                php[0] = ph0;
+                php[M] = phm;
+            }
             lds[lds_pad(0)] = mk2(A.x - B.x, A.x + B.x);
         }
         __syncthreads();
@@ -560,7 +592,21 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
 
     if (f1 == a.F && f1 > f0) {
         R *po = a.phase_out + c * p.K;
-        for (int k = tid; k < p.K; k += T) po[k] = php[k];  // php is stable: last barrier passed
+        if constexpr (PHASE_REGS) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const unsigned pr = tid + m * T;
+                const unsigned pe = pr == 0 ? M / 2 : pr;
+                po[pe] = phr[2 * m];
+                po[M - pe] = phr[2 * m + 1];  // (thread 0, m = 0: the same bin and the same value twice)
+            }
+            if (tid == 0) {
+                po[0] = ph0;
+                po[M] = phm;
+            }
+        } else {
+            for (int k = tid; k < p.K; k += T) po[k] = php[k];  // php is stable: last barrier passed
+        }
         if (OLA) {
             // tail after the last frame: the remaining N - H partial sums, then the zero padding of
             // the last chunk (sumFramesE, Frames.hs:45-47)
