@@ -92,6 +92,38 @@ static int scenario_f32(int n, int h, int channels, int frames)
     return 0;
 }
 
+// Entry points that take "device" pointers (plain host memory in this build): frame maps with
+// entries outside the array, 16-bit PCM, addFrames, the split analysis / synthesis pair.
+static int scenario_dev(int n, int h, int channels, int frames)
+{
+    voc_ctx *ctx = nullptr;
+    const auto win = hann(n);
+    OK(voc_ctx_create(n, h, win.data(), n, 0, VOC_PRECISION_F64, &ctx));
+    const int64_t k = voc_freq_frame_length(ctx), ldk = (k + 1) & ~(int64_t)1;
+    const int64_t len = n + (int64_t)h * (frames - 1);
+    std::vector<int16_t> pcm((size_t)channels * len);
+    for (size_t i = 0; i < pcm.size(); ++i) pcm[i] = (int16_t)((i * 2654435761u) >> 16);
+    std::vector<double> x((size_t)channels * len);
+    OK(voc_pcm16_to_planar_dev(ctx, pcm.data(), len, channels, x.data(), len, nullptr));
+    std::vector<double> mag((size_t)channels * frames * ldk), inc(mag.size()), ph((size_t)channels * k, 0.0);
+    OK(voc_analysis_signal_dev(ctx, x.data(), len, frames, channels, ph.data(), mag.data(), inc.data(), ldk, 1, nullptr));
+    OK(voc_add_frames_dev(ctx, mag.data(), inc.data(), mag.data(), inc.data(), mag.data(), inc.data(), (int64_t)mag.size(),
+                          nullptr));
+    const int64_t fo = 2 * frames + 3;                       // more output frames than input rows
+    std::vector<int64_t> rows((size_t)fo);
+    for (int64_t j = 0; j < fo; ++j) rows[(size_t)j] = j / 2 - 1;   // -1 at the front, past the end at the back
+    const int64_t ylen = (fo - 1) * h + n;
+    std::vector<double> y((size_t)channels * ylen), sph((size_t)channels * k, 0.0);
+    OK(voc_synthesis_mapped_dev(ctx, mag.data(), frames, rows.data(), inc.data(), frames, rows.data(), ldk, fo, channels,
+                                sph.data(), y.data(), ylen, ylen, nullptr));
+    std::vector<int16_t> out((size_t)channels * ylen);
+    OK(voc_planar_to_pcm16_dev(ctx, y.data(), ylen, ylen, channels, 0, out.data(), nullptr));
+    OK(voc_planar_to_pcm16_dev(ctx, y.data(), ylen, ylen, channels, 1, out.data(), nullptr));
+    OK(voc_ctx_destroy(ctx));
+    std::printf("ok  dev N=%d C=%d\n", n, channels);
+    return 0;
+}
+
 int main()
 {
     int bad = 0;
@@ -101,6 +133,11 @@ int main()
     bad |= scenario(1024, 1000, 250, 1, 6, 100);   // fast kernels, scalar loads
     bad |= scenario(100, 81, 20, 2, 8, 20);        // chirp-z
     bad |= scenario(7, 7, 2, 1, 12, 3);
+    bad |= scenario_dev(64, 16, 2, 9);
+    bad |= scenario_dev(1024, 256, 3, 7);          // specialised kernels through the frame maps
+    bad |= scenario_dev(2048, 512, 2, 6);          // registers for the accumulated phases, rows loaded at use
+    bad |= scenario(2048, 2048, 512, 1, 6, 512);
+    bad |= scenario_dev(100, 20, 1, 6);            // chirp-z
     bad |= scenario_f32(64, 16, 2, 9);
     bad |= scenario_f32(1024, 256, 1, 7);
     std::printf(bad ? "FAILURES\n" : "all scenarios ran\n");
