@@ -108,7 +108,7 @@ template <int LOG2M>
 __global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p, FilterProg prog,
                                                                         double *__restrict__ mag,
                                                                         double *__restrict__ inc, long long ldk,
-                                                                        long long rows)
+                                                                        long long rows, long long F, long long rpc)
 {
     using Cf = FiltCfg<LOG2M>;
     constexpr int T = Cf::T, NE = Cf::NE;
@@ -118,7 +118,9 @@ __global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p
     const int tid = threadIdx.x;
     const double ee = 5.9604644775390625e-08;  // 2**(-24), Filter.hs:147
     for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
-        double *mrow = mag + row * ldk, *irow = inc + row * ldk;
+        // row = channel * F + frame; the arrays hold rpc >= F rows per channel
+        const long long prow = rpc == F ? row : (row / F) * rpc + row % F;
+        double *mrow = mag + prow * ldk, *irow = inc + prow * ldk;
         double m[NE], ic[NE];
 #pragma unroll
         for (int j = 0; j < NE; ++j) {

@@ -600,6 +600,7 @@ struct AnaArgsT {
     R *spec;                // SPEC_OUT: [(c*F + f)*K + k] complex
     long long ldk;
     long long F;
+    long long rpc;          // rows per channel in mag / inc / spec: F, or more when the caller's arrays hold other rows too
     int tile_len, tiles;
     R vol;                  // factor folded into mag (volumeFix), 1 for the plain stage
 };
@@ -652,7 +653,7 @@ __global__ void __launch_bounds__(Cfg<LOG2M>::T, 4) analysis_kernel(ParamsT<R> p
         };
         fft_passes<M, T, 1>(lds, p.twP, tid, loader);
         // ---- real-FFT split + per-bin analysis.  Z[k] is at lds[pad(k)].
-        const long long row = c * a.F + f;
+        const long long row = c * a.rpc + f;
 #pragma unroll
         for (int m = 0; m < NP; ++m) {
             const int pr = tid + m * T;
@@ -1006,14 +1007,14 @@ __global__ void phase_carry_kernel(ParamsT<R> p, const R *__restrict__ inc, long
 // order (synthesisStep, Vocoder.hs:190).  Used where only the phase a run of frames ends on is
 // needed (time-sharded runs exchange it between segments).
 __global__ void phase_advance_kernel(Params p, const double *__restrict__ inc, long long ldk, long long F,
-                                     double *__restrict__ phase_io, long long channels)
+                                     double *__restrict__ phase_io, long long channels, long long rpc)
 {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= channels * p.K) return;
     const long long c = g / p.K;
     const int k = (int)(g % p.K);
     double ph = phase_io[g];
-    const double *src = inc + c * F * ldk + k;
+    const double *src = inc + c * rpc * ldk + k;  // rpc rows per channel, the first F of them folded
     long long f = 0;
     for (; f + 16 <= F; f += 16) {
         double dd[16];

@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(Cfg<LOG2L>::T) analysis_blue_kernel(Params p, 
             return make_double2(v * w.x, -(v * w.y));
         });
         blue_convolve<LOG2L>(lds, p, b, tid);
-        const long long row = c * a.F + f;
+        const long long row = c * a.rpc + f;
 #pragma unroll
         for (int q = 0; q < kBlueBins; ++q) {
             const int k = tid + q * T;

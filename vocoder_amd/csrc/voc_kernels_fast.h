@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
             }
         });
 
-        const long long row = c * a.F + f;
+        const long long row = c * a.rpc + f;
         R *mrow = a.mag + row * a.ldk, *irow = a.inc + row * a.ldk;
 VOC_UNROLL(VOC_POLAR_UNROLL)
         for (int m = 0; m < 4; ++m) {

@@ -415,6 +415,7 @@ void analysis_stage_dev(voc_ctx *c, double *phase_io, const double *frames, doub
     a.inc = inc;
     a.ldk = c->K;
     a.F = F;
+    a.rpc = F;
     a.tile_len = analysis_tile_len(c, C, F);
     a.tiles = (int)((F + a.tile_len - 1) / a.tile_len);
     a.vol = 1.0;
@@ -458,8 +459,9 @@ void synthesis_stage_dev(voc_ctx *c, double *phase_io, const double *mag, const 
 
 // genFramesOfE + analysisStage (+ volumeFix) on signal rows: frame j of a channel is read in place
 // at sample j*H (Frames.hs:34-35).
+// rpc: rows per channel of mag / inc (0: F); with more, mag / inc point at the row frame 0 goes to
 void analysis_signal_dev(voc_ctx *c, const double *x, long long x_stride, long long F, long long C, double *phase_io,
-                         double *mag, double *inc, long long ldk, bool volume_fix, hipStream_t st)
+                         double *mag, double *inc, long long ldk, bool volume_fix, hipStream_t st, long long rpc = 0)
 {
     if (C <= 0 || F <= 0) return;
     ensure_ws(c, (size_t)C * c->K * sizeof(double));
@@ -475,6 +477,7 @@ void analysis_signal_dev(voc_ctx *c, const double *x, long long x_stride, long l
     a.inc = inc;
     a.ldk = ldk;
     a.F = F;
+    a.rpc = rpc ? rpc : F;
     a.tile_len = analysis_tile_len(c, C, F);
     a.tiles = (int)((F + a.tile_len - 1) / a.tile_len);
     a.vol = volume_fix ? c->vol : 1.0;
@@ -545,13 +548,13 @@ void synthesis_signal_dev(voc_ctx *c, const double *mag, const double *inc, long
 }
 
 void phase_advance_dev(voc_ctx *c, const double *inc, long long ldk, long long F, long long C, double *phase_io,
-                       hipStream_t st)
+                       hipStream_t st, long long rpc = 0)
 {
     if (C <= 0 || F <= 0) return;
     const long long chains = C * c->K;
     LaunchTimer timer(c, KIND_CARRY, st);
     hipLaunchKernelGGL(voc::phase_advance_kernel, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, c->params, inc,
-                       ldk, F, phase_io, C);
+                       ldk, F, phase_io, C, rpc ? rpc : F);
     HIPCHK(hipGetLastError());
 }
 
@@ -689,6 +692,7 @@ void roundtrip_dev(voc_ctx *c, const R *x, long long x_stride, long long len, lo
         a.inc = inc;
         a.ldk = r.ldk;
         a.F = F;
+        a.rpc = F;
         a.tile_len = r.ana_tile;
         a.tiles = r.ana_tiles;
         a.vol = (R)c->vol;  // volumeFix folded into the magnitude store (Conduit.hs:34-35)
@@ -986,6 +990,7 @@ int32_t spec_forward(voc_ctx *c, const double *in, double *out, int64_t B)
         a.frame_stride = (long long)in_len;
         a.spec = dout.d();
         a.F = B;
+        a.rpc = B;
         a.tile_len = 4;
         a.tiles = (int)((B + 3) / 4);
         a.vol = 1.0;
