@@ -1,7 +1,7 @@
 #!/bin/bash
-# Collects the round's profile evidence on the GPU box: bench line, rocprofv3 kernel statistics of the
+# Collects the profile evidence of bench.py on the GPU box: bench line, rocprofv3 kernel statistics of the
 # same command, and hardware counters in separate passes (one counter group per run).  Results land
-# under gpurun_out/profile/ as small text / csv files.   usage: bash tools/profile_round.sh
+# under gpurun_out/profile/ as small text / csv files.   usage: bash tools/profile_bench.sh
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 out=gpurun_out/profile
