@@ -7,8 +7,15 @@ A step is one pass of the fused round trip (framing, window, R2C FFT, phase anal
 phase accumulation, polar synthesis, C2R IFFT, window, overlap-add) over the batch of the metric
 configuration: 1024 mono streams x 60 s at 48 kHz per GPU, N = W = 4096, H = 1024, fp64, identity
 filter, Hann window, synthetic signals generated in HBM before the timed region.  With N > 1 the
-script is started once per GPU by torch.distributed.run; streams are independent, so every rank
-owns its own 1024 streams and there is no collective on the data path (weak scaling).
+script runs once per GPU under torch.distributed.run -- started that way by the caller, or, when
+called plainly as `python bench.py --gpus N`, by this script itself (the parent starts the ranks as
+child processes before it touches a GPU and relays rank 0's line).  Streams are independent, so every
+rank owns its own 1024 streams and there is no collective on the data path (weak scaling).
+
+`--mode timeshard` times the other way of using several GPUs instead: few, long streams cut by time,
+every rank owning a run of consecutive frames (64 channels x --minutes per GPU, walked in runs of
+frames with the signal generated in HBM run by run), with the one exchange step of the path -- an
+all-gather of the per-rank phase advance and a neighbour exchange of the overlap-add tail -- on RCCL.
 
 Rank 0 prints one JSON line.  `roofline` is for the slower of the two kernels of a step, its
 duration measured with HIP events on the launch stream; `cpu_baseline` times the CPU oracle (a C
@@ -28,6 +35,9 @@ import torch  # noqa: E402
 
 N_FFT, HOP, RATE, SECONDS = 4096, 1024, 48000, 60
 HBM_PEAK = 8.0e12                                  # B/s, MI355X HBM3E
+FP64_PEAK = 78.6e12                                # flop/s, MI355X fp64 vector
+FLOP_FRAME = 1.0e6                                 # fp64 flop of one frame's round trip: 2 FFTs of 2048 complex points
+                                                   # (~2.5e5) + 2049 bins x (magnitude, atan2, wrap, sin, cos) (~7e5)
 K_BINS = N_FFT // 2 + 1
 BYTES_ANALYSIS = 8 * HOP + 16 * K_BINS             # unique input samples in, (mag, ph_inc) out
 BYTES_SYNTHESIS = 16 * K_BINS + 8 * HOP            # (mag, ph_inc) in, unique output samples out
@@ -79,6 +89,69 @@ def cpu_baseline_all_cores(window, x_sample, cores):
     return frames / dt, frames, dt
 
 
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` called plainly: start the N ranks as child processes of a parent that
+    has not touched a GPU, pass their output through (rank 0 prints the JSON line) and exit with
+    the launcher's status."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
+def timeshard_mode(args, world, rank, dev, red_dev, D):
+    """Few long streams cut by time over the ranks (weak scaling: every rank owns --minutes of signal)."""
+    from vocoder_amd import vocoder as V, timeshard as T, window as Wn
+    par = V.VocoderParams(N_FFT, HOP, Wn.hann_window(N_FFT), device=dev.index)
+    c = args.channels
+    length = int(args.minutes * 60 * RATE) * world
+    freqs = (110.0 * 2.0 ** ((torch.arange(c, device=dev) % 72) / 12.0)).double()[:, None]
+
+    def source(lo, hi):                                 # generated where it is used: the whole signal is never resident
+        t = torch.arange(lo, hi, device=dev, dtype=torch.float64)[None, :]
+        return 0.5 * torch.sin((2 * np.pi / RATE) * freqs * t)
+
+    acc = torch.zeros((), dtype=torch.float64, device=dev)
+
+    def sink(lo, y):
+        acc.add_(y.square().sum())
+
+    def fence():
+        torch.cuda.synchronize()
+        D.barrier()
+        torch.cuda.synchronize()
+
+    stats = {}
+    for _ in range(args.warmup):
+        T.process_pieces(par, source, length, args.piece, sink=sink)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        T.process_pieces(par, source, length, args.piece, sink=sink, stats=stats)
+    fence()
+    dt = D.max_over_ranks(time.perf_counter() - t0, red_dev)
+    exch = D.max_over_ranks(stats.get("exchange_s", 0.0), red_dev)
+    if rank == 0:
+        frames = par.lib.dll.voc_num_frames(par.handle, length) * c
+        print(json.dumps({
+            "metric": "STFT frames/sec analysis+synthesis (N=4096,hop=1024,fp64), long streams cut by time",
+            "value": frames * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{c} channels x {args.minutes} min @48 kHz per GPU, N=W=4096 hop=1024 fp64 identity "
+                                   f"round-trip (Hann), cut by time over {world} rank(s), runs of {args.piece} frames",
+                       "sharding": "by time segment: halo frame, all-gather of the phase advance, neighbour tail exchange",
+                       "walks_per_step": 2 if world > 1 else 1},
+            "exchange_ms_per_step": exch / args.steps * 1e3,
+        }), flush=True)
+    D.finish()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,7 +164,15 @@ def main():
     ap.add_argument("--cpu-streams", type=int, default=24, help="streams of the workload the CPU oracle is timed on")
     ap.add_argument("--backend", default="nccl", help="process-group backend (gloo: rehearsal of the multi-rank path without RCCL)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0")
+    ap.add_argument("--mode", choices=("streams", "timeshard"), default="streams",
+                    help="streams: the metric (streams sharded over GPUs); timeshard: long streams cut by time")
+    ap.add_argument("--channels", type=int, default=64, help="timeshard: channels of the long signal")
+    ap.add_argument("--minutes", type=float, default=10.0, help="timeshard: minutes of signal per GPU")
+    ap.add_argument("--piece", type=int, default=8192, help="timeshard: frames per run")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args.gpus)          # before anything touches a GPU in this process
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -105,6 +186,8 @@ def main():
     from vocoder_amd import distributed as D
     D.init(args.backend, dev)
     red_dev = dev if args.backend == "nccl" else "cpu"   # where the one reduced scalar lives
+    if args.mode == "timeshard":
+        return timeshard_mode(args, world, rank, dev, red_dev, D)
 
     from vocoder_amd import vocoder as V, conduit as Cd, window as Wn
     win = Wn.hann_window(N_FFT)
@@ -167,14 +250,34 @@ def main():
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9), "traffic": None},
         }
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, if collected
+        # PMC-derived figures are not measured in this run: they come from the committed counter passes of
+        # the same command (tools/profile_bench.sh) and say so
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes per launch
         if os.path.exists(tfile):
             try:
                 t = json.load(open(tfile))
                 if t.get("streams_per_gpu") == args.streams and not f32:   # measured on this workload only
                     out["roofline"]["traffic"] = t.get(names[dom])
+                    out["roofline"]["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc passes over this command)"
             except Exception:
                 pass
+        # The kernels sit past the ridge: fp64 vector issue, not HBM, is what they saturate.  Reported
+        # beside the HBM figure: the whole path against the fp64 vector peak (algorithmic flop count),
+        # and, from the counter passes, vector instructions per wave and frame and the busy fraction.
+        if not f32:
+            fp = {"peak": FP64_PEAK / 1e12, "unit": "TFLOP/s", "flop_per_frame": FLOP_FRAME,
+                  "achieved": value / world * FLOP_FRAME / 1e12, "frac": value / world * FLOP_FRAME / FP64_PEAK}
+            vfile = os.path.join(ROOT, "profiles", "valu.json")
+            if os.path.exists(vfile):
+                try:
+                    v = json.load(open(vfile))
+                    if v.get("streams_per_gpu") == args.streams:
+                        fp["instr_per_wave_frame"] = v.get("instr_per_wave_frame")
+                        fp["valu_busy_frac"] = v.get("valu_busy_frac")
+                        fp["counters_source"] = "profiles/valu.json (rocprofv3 --pmc passes over this command)"
+                except Exception:
+                    pass
+            out["roofline"]["fp64_valu"] = fp
         if world == 1 and not args.no_cpu_baseline:
             ncpu = min(args.cpu_streams, c)
             v, nfr, secs = cpu_baseline(win, x[:ncpu].double().cpu().numpy())
