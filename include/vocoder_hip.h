@@ -25,7 +25,12 @@
  *     a HIP stream (hipStream_t passed as void*, NULL = the default stream) and
  *     return after enqueueing.
  *   - a context may be used from any thread; calls on one context serialise on
- *     an internal mutex (the reference leaves this open: Vocoder.hs:98).
+ *     an internal mutex (the reference leaves this open: Vocoder.hs:98).  `_dev` calls on one
+ *     context may name different HIP streams: the library orders its own workspace between
+ *     them with an event (a call waits, on its stream, for the previous call's use of the
+ *     workspace to finish); ordering the caller's buffers between streams is the caller's
+ *     business, as with any stream-ordered API.  A voc_stream is one sequential state: its
+ *     pushes must be ordered by the caller (one HIP stream, or synchronised).
  */
 #ifndef VOCODER_HIP_H
 #define VOCODER_HIP_H
@@ -109,6 +114,16 @@ int32_t voc_add_frames(voc_ctx *ctx, const double *mag1, const double *inc1, con
  * chains run on copies of an STFT this is addFilters (Filter.hs:58-59). */
 int32_t voc_add_frames_dev(voc_ctx *ctx, const double *mag1, const double *inc1, const double *mag2, const double *inc2,
                            double *mag_out, double *inc_out, int64_t count, void *stream);
+
+/* Element-wise combination of two STFT streams, as the `--multiply`, `--divide` and `--add` commands of
+ * vocoder-jack combine them (vocoder-dunai/example/VocoderJack.hs:107-110,127-135):
+ *   VOC_BINARY_MULTIPLY  mkBinary (*) (+): mag1 * mag2, ph_inc1 + ph_inc2
+ *   VOC_BINARY_DIVIDE    mkBinary (/) (-): mag1 / mag2, ph_inc1 - ph_inc2
+ *   VOC_BINARY_ADD       addFrames (the same as voc_add_frames_dev)
+ * over `count` doubles of six device arrays with one common layout; an output may be one of the inputs. */
+enum { VOC_BINARY_MULTIPLY = 0, VOC_BINARY_DIVIDE = 1, VOC_BINARY_ADD = 2 };
+int32_t voc_binary_frames_dev(voc_ctx *ctx, int32_t op, const double *mag1, const double *inc1, const double *mag2,
+                              const double *inc2, double *mag_out, double *inc_out, int64_t count, void *stream);
 
 /* ---- stage level (the batched hot path) -----------------------------------------------
  * voc_analysis_stage  replaces analysisStage par ph frames           Vocoder.hs:149-150
@@ -245,9 +260,14 @@ int32_t voc_synthesis_mapped_dev(voc_ctx *ctx, const double *mag, int64_t mag_fr
  *   VOC_FILTER_RANDOM_PHASE            seed < 2^53 randomPhaseFilter       Filter.hs:156-157
  * The reference draws randomPhaseFilter's increments from the unseeded global generator, so
  * its values are not reproducible; here they are Philox-4x32-10 words keyed by the seed with
- * counter (bin, row, position in the chain), row = channel * nframes + frame.
+ * counter (bin | position in the chain << 16, channel, frame low word, frame high word), where
+ * channel and frame are positions in the WHOLE signal: a signal filtered in pieces (chunks of a
+ * stream, runs of a time-sharded segment, blocks of channels on different GPUs) draws the numbers
+ * one call over all of it would draw, and every frame draws fresh ones as in the reference.
  * voc_filter_apply[_dev] runs the chain in place on mag / ph_inc ([C][F][K] host arrays, or
- * device arrays with row pitch ldk).  At most 12 operations per chain (VOC_ERR_SIZE beyond).
+ * device arrays with row pitch ldk), taking row 0 for frame 0 of channel 0;
+ * voc_filter_apply_at_dev says where in the signal the rows sit (first_frame, first_channel).
+ * A voc_stream passes its own frame count.  At most 12 operations per chain (VOC_ERR_SIZE beyond).
  * addFilters (Filter.hs:58-59): run the two chains on copies and add them with voc_add_frames[_dev].
  */
 typedef struct voc_filter voc_filter;
@@ -277,6 +297,8 @@ int32_t voc_filter_append(voc_filter *f, int32_t kind, const double *params, int
 int32_t voc_filter_apply(voc_filter *f, double *mag, double *ph_inc, int64_t nframes, int64_t channels);
 int32_t voc_filter_apply_dev(voc_filter *f, double *mag, double *ph_inc, int64_t ldk, int64_t nframes,
                              int64_t channels, void *stream);
+int32_t voc_filter_apply_at_dev(voc_filter *f, double *mag, double *ph_inc, int64_t ldk, int64_t nframes,
+                                int64_t channels, int64_t first_frame, int64_t first_channel, void *stream);
 
 /* ---- playSpeed (vocoder-conduit/src/Vocoder/Conduit/Filter.hs:122-136) --------------------------
  * playSpeed coeff replicates or drops STFT frames: after i input frames floor(i * coeff) frames

@@ -212,6 +212,19 @@ def add_frames(mag1, inc1, mag2, inc2):
     return mo, io
 
 
+def binary_frames(op: str, mag1, inc1, mag2, inc2):
+    """mkBinary op1 op2 (vocoder-dunai/example/VocoderJack.hs:107-110) as vocoder-jack instantiates it:
+    `--multiply` = mkBinary (*) (+) (:127-129), `--divide` = mkBinary (/) (-) (:130-132); zipWith over
+    the moduli and over the phase increments, one IEEE operation per element."""
+    m1, i1, m2, i2 = (_f64(a) for a in (mag1, inc1, mag2, inc2))
+    if op == "multiply":
+        return m1 * m2, i1 + i2
+    if op == "divide":
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return m1 / m2, i1 - i2
+    raise ValueError(op)
+
+
 def num_frames(length: int, w: int, hop: int) -> int:
     return lib().orc_num_frames(int(length), int(w), int(hop))
 
@@ -288,6 +301,13 @@ def sum_frames_e(chunk_size: int, hop: int, frames, dtype=np.float64):
             C.c_int64(len(frames)), out.ctypes.data_as(ptr), C.c_int64(maxc))
     assert nc <= maxc
     return out[:nc].copy()
+
+
+def sum_frames_e_schedule(chunk_size: int, hop: int, nframes: int) -> np.ndarray:
+    """published[f] = chunks sumFramesE has yielded once frame f has been awaited (Frames.hs:49-53)."""
+    out = np.zeros(max(nframes, 0), dtype=np.int64)
+    lib().orc_sum_frames_e_schedule(C.c_int64(chunk_size), C.c_int64(hop), C.c_int64(nframes), out.ctypes.data_as(_ip))
+    return out
 
 
 def frames_of_s(chunk_size: int, hop: int, ticks, dtype=np.float64):

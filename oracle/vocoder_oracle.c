@@ -493,6 +493,23 @@ ORC_API void orc_make_window(int kind, double alpha, int n, double *out)
 /* Framing and overlap-add: instantiated for double and int64                */
 /* ------------------------------------------------------------------------ */
 
+/* Publication schedule of sumFramesE (Frames.hs:49-53), data left out: published[f] = chunks yielded
+ * once frame f has been awaited.  `process` appends the frame at offset `sofar`; `process2` publishes
+ * while a whole chunk lies before that offset (sofar >= chunkSize), then the offset moves on by a hop. */
+ORC_API void orc_sum_frames_e_schedule(int64_t chunk_size, int64_t hop, int64_t nframes, int64_t *published)
+{
+    int64_t sofar = 0, nch = 0, f;
+    for (f = 0; f < nframes; f++) {
+        while (sofar >= chunk_size) {
+            nch++;
+            sofar -= chunk_size;
+        }
+        sofar += hop;
+        published[f] = nch;
+    }
+}
+
+
 #define T double
 #define SUF(name) name##_f64
 #include "frames_generic.inc"

@@ -144,14 +144,15 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     return c
 
 
-def random_phase_expected(seed, rows, k, position):
-    """ph_inc the library's random-phase operation writes: 53 bits of Philox words 0,1 scaled to
-    [0, 2 pi); counter (bin, row low, row high, position in the chain), key = seed."""
+def random_phase_expected(seed, channels, frames, k, position, first_frame=0, first_channel=0):
+    """ph_inc the library's random-phase operation writes, shape (channels, frames, k): 53 bits of
+    Philox words 0,1 scaled to [0, 2 pi); counter (bin | position in the chain << 16, channel,
+    frame low, frame high) with channel and frame counted in the whole signal, key = seed."""
     import numpy as np
-    bins = np.arange(k, dtype=np.uint64)[None, :]
-    row = np.arange(rows, dtype=np.uint64)[:, None]
-    r = philox4x32_10(bins, row & np.uint64(0xFFFFFFFF), row >> np.uint64(32), np.uint64(position),
-                      seed & 0xFFFFFFFF, seed >> 32)
+    bins = (np.arange(k, dtype=np.uint64) | (np.uint64(position) << np.uint64(16)))[None, None, :]
+    ch = (np.arange(channels, dtype=np.uint64) + np.uint64(first_channel))[:, None, None]
+    fr = (np.arange(frames, dtype=np.uint64) + np.uint64(first_frame))[None, :, None]
+    r = philox4x32_10(bins, ch, fr & np.uint64(0xFFFFFFFF), fr >> np.uint64(32), seed & 0xFFFFFFFF, seed >> 32)
     bits = ((r[0] << np.uint64(32)) | r[1]) >> np.uint64(11)
     return (bits.astype(np.float64) * 2.0 ** -53) * (2 * np.pi)
 

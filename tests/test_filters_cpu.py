@@ -105,7 +105,7 @@ def test_random_phase_is_the_documented_philox_stream(par):
     seed = 0x1234_5678_9ABC
     m, i = (Fl.amplify(1.0) >> Fl.random_phase_filter(seed)).bind(par, 1.0).apply(mag, inc)
     assert np.array_equal(m, mag)
-    exp = random_phase_expected(seed, 6, par.K, position=1).reshape(2, 3, par.K)
+    exp = random_phase_expected(seed, 2, 3, par.K, position=1)
     assert np.array_equal(i, exp)
     assert i.min() >= 0 and i.max() < 2 * np.pi and abs(i.mean() - np.pi) < 0.2
 
@@ -324,3 +324,25 @@ def test_add_filters_matches_oracle(par, orc):
     assert mr is None and ir is None and fo == 4 and torch.equal(ml[..., :par.K], md[..., :par.K])
     with pytest.raises(ValueError):
         Fl.add_filters(Fl.play_speed(2), Fl.id_filter()).bind(par, step).frames_out(4)
+
+
+def test_binary_stream_operations_match_the_reference_definition(par, orc):
+    """`--multiply` = mkBinary (*) (+), `--divide` = mkBinary (/) (-) (VocoderJack.hs:107-110,127-132);
+    `add` is addFrames."""
+    import torch
+    from vocoder_amd import conduit as Cd, vocoder as V
+    rng = np.random.default_rng(31)
+    shape = (2, 3, par.K)
+    m1, m2 = rng.uniform(0, 2, shape), rng.uniform(0.1, 2, shape)
+    i1, i2 = rng.uniform(-1, 1, shape), rng.uniform(-1, 1, shape)
+    m2[0, 0, 0] = 0.0                                        # division by a zero modulus: IEEE infinity / NaN, as in Haskell
+    m1[0, 0, 1], m2[0, 0, 1] = 0.0, 0.0
+    t = [torch.from_numpy(a.copy()) for a in (m1, i1, m2, i2)]
+    for op in ("multiply", "divide"):
+        mo, io = Cd.binary_frames_dev(par, op, (t[0], t[1]), (t[2], t[3]))
+        me, ie = orc.binary_frames(op, m1, i1, m2, i2)
+        assert np.array_equal(mo.numpy(), me, equal_nan=True) and np.array_equal(io.numpy(), ie)
+    mo, io = Cd.binary_frames_dev(par, "add", (t[0], t[1]), (t[2], t[3]))
+    ma, ia = V.add_frames(par, (m1, i1), (m2, i2))
+    assert np.array_equal(mo.numpy(), ma, equal_nan=True) and np.array_equal(io.numpy(), ia, equal_nan=True)
+    assert par.lib.dll.voc_binary_frames_dev(par.handle, 9, None, None, None, None, None, None, 0, None) == -1

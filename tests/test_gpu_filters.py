@@ -81,7 +81,7 @@ def test_random_phase_stream_on_device(gpu_lib):
     m, i = Fl.random_phase_filter(77).bind(par, 1.0).apply_dev(mag, inc)
     torch.cuda.synchronize()
     assert torch.equal(m, keep)
-    exp = random_phase_expected(77, c * f, par.K, position=0).reshape(c, f, par.K)
+    exp = random_phase_expected(77, c, f, par.K, position=0)
     assert np.array_equal(i.cpu().numpy()[..., :par.K], exp)
 
 
@@ -181,3 +181,60 @@ def test_add_filters_on_device(gpu_lib, orc):
             assert np.allclose(md[ch, fr], me, rtol=1e-12, atol=1e-15)
             live = me > 1e-9
             assert np.abs(np.angle(np.exp(1j * (idv[ch, fr] - ie))))[live].max() <= 1e-9
+
+
+def _oracle_speed_then_random_phase(orc, n, hop, win, x, speed, seed, channel):
+    """`--playSpeed s --randomPhase` (VocoderFile.hs:72 folds the filters left to right) on one channel
+    from oracle pieces: analysis .| volumeFix, playSpeed's frame map, increments replaced by the
+    library's documented random stream (the reference's own generator is unseeded), synthesisStage,
+    sumFramesE."""
+    k = n // 2 + 1
+    rt = orc.roundtrip(n, hop, win, x, want_stft=True)
+    src = orc.play_speed(speed.numerator, speed.denominator, rt["mag"].shape[0])
+    mag = rt["mag"][src]
+    inc = random_phase_expected(seed, 1, mag.shape[0], k, position=0, first_channel=channel)[0]
+    sph, frames = orc.synthesis_stage(n, hop, win, np.zeros(k), mag, inc)
+    y = np.zeros(orc.ola_length(mag.shape[0], len(win), hop, hop))
+    for j in range(mag.shape[0]):
+        y[j * hop:j * hop + len(win)] = y[j * hop:j * hop + len(win)] + frames[j]
+    return y, sph
+
+
+@pytest.mark.parametrize("n,hop,speed", [(8192, 2048, Fraction(2)), (1024, 256, Fraction(3, 2))])
+def test_play_speed_then_random_phase_matches_oracle(gpu_lib, orc, n, hop, speed):
+    """The time-stretch configuration as written: playSpeed feeding a write-only random-phase pass,
+    synthesis reading the moduli through the row map and the fresh increments directly."""
+    import torch
+    from vocoder_amd import vocoder as V, conduit as Cd, filter as Fl
+    win = _hann(n)
+    par = V.VocoderParams(n, hop, win, lib=gpu_lib)
+    c, seed = 3, 1234
+    x = _signal(c, n + hop * 13 + 5)
+    filt = (Fl.play_speed(speed) >> Fl.random_phase_filter(seed)).bind(par, 48000.0 / n)
+    sph = torch.zeros((c, par.K), dtype=torch.float64, device="cuda")
+    y, _, sph = Cd.process_filter_dev(par, filt, torch.from_numpy(x).cuda(), syn_phase=sph)
+    torch.cuda.synchronize()
+    y, sph = y.cpu().numpy(), sph.cpu().numpy()
+    for ch in range(c):
+        yo, spo = _oracle_speed_then_random_phase(orc, n, hop, win, x[ch], speed, seed, ch)
+        assert y.shape[1] == yo.size
+        assert np.linalg.norm(y[ch] - yo) / np.linalg.norm(yo) <= TOL_L2
+        assert np.array_equal(sph[ch], spo)          # identical increments in, identical phase chain out
+
+
+def test_binary_stream_operations_on_device(gpu_lib, orc):
+    """`--multiply` / `--divide` (VocoderJack.hs:107-110,127-132) on device arrays against the oracle."""
+    import torch
+    from vocoder_amd import vocoder as V, conduit as Cd
+    par = V.VocoderParams(4096, 1024, _hann(4096), lib=gpu_lib)
+    rng = np.random.default_rng(5)
+    shape = (3, 11, par.K + 1)
+    m1, m2 = rng.uniform(0, 2, shape), rng.uniform(0.1, 2, shape)
+    i1, i2 = rng.uniform(-1, 1, shape), rng.uniform(-1, 1, shape)
+    m2[0, 0, :2] = 0.0
+    m1[0, 0, 1] = 0.0
+    t = [torch.from_numpy(a).cuda() for a in (m1, i1, m2, i2)]
+    for op in ("multiply", "divide"):
+        mo, io = Cd.binary_frames_dev(par, op, (t[0], t[1]), (t[2], t[3]))
+        me, ie = orc.binary_frames(op, m1, i1, m2, i2)
+        assert np.array_equal(mo.cpu().numpy(), me, equal_nan=True) and np.array_equal(io.cpu().numpy(), ie)

@@ -229,3 +229,66 @@ def test_lengths_that_are_not_powers_of_two(gpu_lib, orc, n, w, h):
     Hh.check_fft_layer(gpu_lib, orc, n, w, h, rng)
     Hh.check_stages(gpu_lib, orc, n, w, h, 5, 2, rng)
     Hh.check_roundtrip(gpu_lib, orc, n, w, h, w + h * 7 + 3, 2, rng)
+
+
+def test_interleaved_layout_on_device(gpu_lib, orc):
+    """vocoder-audio cuts frames of W*C interleaved samples at hops of H*C and splits each frame per
+    channel (Audio.hs:51-55): de-interleaving once and framing each planar channel at (W, H) gives the
+    same frames; interleave inverts de-interleave; bit exact (data movement only)."""
+    import torch
+    from vocoder_amd import vocoder as V, conduit as Cd
+    w, hop, c = 4096, 1024, 3
+    par = V.VocoderParams(w, hop, np.ones(w), lib=gpu_lib)
+    rng = np.random.default_rng(13)
+    n = w + hop * 6 + 5
+    planar = rng.standard_normal((c, n))
+    inter = planar.T.reshape(-1).copy()
+    got = Cd.deinterleave_dev(par, torch.from_numpy(inter).cuda(), c)
+    assert np.array_equal(got.cpu().numpy(), planar)
+    assert np.array_equal(Cd.interleave_dev(par, got).cpu().numpy(), inter)
+    fr_inter, left = orc.gen_frames_of_e(w * c, hop * c, [inter])          # the reference's interleaved framing
+    frames, leftover = Cd.frames_of_e(par, got.cpu().numpy())
+    for ch in range(c):
+        assert np.array_equal(fr_inter.reshape(-1, w, c)[:, :, ch], frames[ch])
+        assert np.array_equal(left.reshape(-1, c)[:, ch], leftover[ch])
+    par.close()
+
+
+def test_calls_on_two_hip_streams_share_the_context_workspace(gpu_lib, orc):
+    """Stage calls on one context from two different HIP streams: the library orders its own
+    workspace between them, so both results are those of the calls made one after the other."""
+    import ctypes as C
+    import torch
+    from vocoder_amd import vocoder as V
+    n, hop, c, f = 4096, 1024, 48, 40
+    win = orc.make_window("hann", n)
+    par = V.VocoderParams(n, hop, win, lib=gpu_lib)
+    k = par.K
+    rng = np.random.default_rng(77)
+    sets = []
+    for i in range(2):
+        mag = torch.from_numpy(rng.uniform(0, 1, (c, f, k))).cuda()
+        inc = torch.from_numpy(rng.uniform(-0.05, 0.05, (c, f, k))).cuda()
+        ph = torch.from_numpy(rng.uniform(-3, 3, (c, k))).cuda()
+        sets.append((mag, inc, ph))
+    p = lambda t: C.c_void_p(t.data_ptr())
+
+    def run(streams):
+        outs = []
+        for (mag, inc, ph), st in zip(sets, streams):
+            phc, fr = ph.clone(), torch.empty((c, f, n), dtype=torch.float64, device="cuda")
+            with torch.cuda.stream(st):
+                for _ in range(3):                     # several calls back to back on each stream
+                    phc.copy_(ph)
+                    par._call("voc_synthesis_stage_dev", p(phc), p(mag), p(inc), p(fr), c, f, C.c_void_p(st.cuda_stream))
+            outs.append((phc, fr))
+        torch.cuda.synchronize()
+        return outs
+
+    torch.cuda.synchronize()
+    one = torch.cuda.Stream()
+    ref = run([one, one])
+    got = run([torch.cuda.Stream(), torch.cuda.Stream()])
+    for (pa, fa), (pb, fb) in zip(ref, got):
+        assert torch.equal(pa, pb) and torch.equal(fa, fb)
+    par.close()

@@ -70,3 +70,84 @@ def test_dunai_mode_on_device_matches_oracle(gpu_lib, orc):
     y, r = np.concatenate(got), np.concatenate(ref)
     assert y.shape == r.shape
     assert np.linalg.norm(y - r) / np.linalg.norm(r) <= 1e-9
+
+
+def test_concatenated_sources_with_their_own_filters_on_device(gpu_lib, orc):
+    """concatenateV (Audio.hs:60-69) at N=4096: leftover and phases of source 1 flow into source 2,
+    each source runs its own filter, all frames feed one overlap-add; against the oracle."""
+    from helpers import TOL_L2
+    from vocoder_amd import vocoder as V, stream as S, filter as Fl
+    n, hop = 4096, 1024
+    win = _hann(n)
+    par = V.VocoderParams(n, hop, win, lib=gpu_lib)
+    step = 48000.0 / n
+    rng = np.random.default_rng(21)
+    x1, x2 = rng.standard_normal(n + hop * 9 + 7), rng.standard_normal(hop * 11 + 3)
+    f1 = Fl.lowpass_brickwall(6000.0).bind(par, step)
+    f2 = Fl.pitch_shift_interpolate(1.25).bind(par, step)
+    st = S.Stream(par, 1, filt=f1)
+    outs = [st.push(x1)]
+    st.set_filter(f2)
+    outs += [st.push(x2), st.flush()]
+    y = np.concatenate(outs, axis=1)[0]
+    k = n // 2 + 1
+    fr1, left1 = orc.gen_frames_of_e(n, hop, [x1])
+    fr2, left2 = orc.gen_frames_of_e(n, hop, [x2], q0=left1)
+    vc = orc.volume_coeff(hop, win)
+    aph, m1, i1 = orc.analysis_stage(n, hop, win, np.zeros(k), fr1)
+    aph, m2, i2 = orc.analysis_stage(n, hop, win, aph, fr2)
+    m1, i1 = orc.apply_filter(step, [("lowpass_brickwall", 6000.0)], m1 * vc, i1)
+    m2, i2 = orc.apply_filter(step, [("pitch_shift", 1.25)], m2 * vc, i2)
+    _, frames = orc.synthesis_stage(n, hop, win, np.zeros(k), np.concatenate([m1, m2]), np.concatenate([i1, i2]))
+    ref = orc.sum_frames_e(hop, hop, list(frames)).ravel()
+    assert y.size == ref.size
+    assert np.linalg.norm(y - ref) / np.linalg.norm(ref) <= TOL_L2
+    assert np.array_equal(st.leftover()[0], left2)
+
+
+@pytest.mark.parametrize("n,w,hop,chunk", [(4096, 4096, 1024, 1024), (4096, 3000, 1000, 4096), (256, 256, 64, 100)])
+def test_stream_publishes_when_sum_frames_e_would(gpu_lib, orc, n, w, hop, chunk):
+    """After every push the stream has published exactly the chunks the oracle's sumFramesE state
+    machine (Frames.hs:49-53) has yielded for the frames cut so far, and the samples are the oracle's."""
+    from helpers import TOL_L2
+    from vocoder_amd import vocoder as V, stream as S
+    win = _hann(w)
+    par = V.VocoderParams(n, hop, win, lib=gpu_lib)
+    rng = np.random.default_rng(n + w)
+    total = w + hop * 29 + 13
+    x = rng.standard_normal(total)
+    cuts = np.concatenate([[0], np.sort(rng.integers(0, total + 1, 9)), [total]])
+    pieces = [x[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    st = S.Stream(par, 1, chunk)
+    got, frames_so_far = [], 0
+    for i, piece in enumerate(pieces):
+        got.append(st.push(piece)[0])
+        fr, _ = orc.gen_frames_of_e(w, hop, pieces[: i + 1])          # the reference's framing of the pieces so far
+        frames_so_far = fr.shape[0]
+        sched = orc.sum_frames_e_schedule(chunk, hop, frames_so_far)
+        assert sum(g.size for g in got) == (sched[-1] if frames_so_far else 0) * chunk
+    got.append(st.flush()[0])
+    y = np.concatenate(got)
+    r = orc.roundtrip(n, hop, win, x, chunk=chunk)
+    assert y.shape == r["y"].shape and np.linalg.norm(y - r["y"]) / np.linalg.norm(r["y"]) <= TOL_L2
+
+
+def test_random_phase_stream_hop_by_hop_on_device(gpu_lib):
+    """A stream pushed one hop at a time with randomPhase equals the one-call result (the random
+    increments are keyed by the frame's position in the signal, not in the push)."""
+    import torch
+    from vocoder_amd import vocoder as V, conduit as Cd, stream as S, filter as Fl
+    n, hop, c = 4096, 1024, 2
+    par = V.VocoderParams(n, hop, _hann(n), lib=gpu_lib)
+    filt = Fl.random_phase_filter(9).bind(par, 48000.0 / n)
+    x = torch.randn((c, n + hop * 10 + 5), dtype=torch.float64, device="cuda")
+    y_ref, _, s_ref = Cd.process_filter_dev(par, filt, x)
+    st = S.Stream(par, c, filt=filt)
+    outs, pos = [], 0
+    for m in [n] + [hop] * 10 + [5]:
+        outs.append(st.push_dev(x[:, pos:pos + m].contiguous(), m))
+        pos += m
+    torch.cuda.synchronize()
+    y = np.concatenate([o.cpu().numpy() for o in outs] + [st.flush()], axis=1)
+    assert np.array_equal(y, y_ref.cpu().numpy())
+    assert np.array_equal(st.phases()[1], s_ref.cpu().numpy())

@@ -199,3 +199,33 @@ def test_concatenated_sources_with_their_own_filters(emu_lib, orc):
     ref = orc.sum_frames_e(hop, hop, list(frames)).ravel()
     assert y.size == ref.size
     assert np.linalg.norm(y - ref) / np.linalg.norm(ref) <= TOL_L2
+
+
+def test_random_phase_does_not_depend_on_the_chunking(emu_lib):
+    """randomPhaseFilter draws fresh increments for every frame (Filter.hs:156-157), however the
+    frames arrive: a stream pushed hop by hop gives the one-call result, and consecutive frames of a
+    channel get different increments."""
+    import torch
+    from helpers import random_phase_expected
+    from vocoder_amd import vocoder as V, conduit as Cd, stream as S, filter as Fl
+    n, hop, c = 128, 32, 2
+    par = V.VocoderParams(n, hop, _hann(n), lib=emu_lib)
+    filt = Fl.random_phase_filter(9).bind(par, 375.0)
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((c, n + hop * 12 + 5))
+    y_ref, _, s_ref = Cd.process_filter_dev(par, filt, torch.from_numpy(x))
+    st = S.Stream(par, c, filt=filt)
+    outs, pos = [], 0
+    for m in [n] + [hop] * 12 + [5]:
+        outs.append(st.push(x[:, pos:pos + m]))
+        pos += m
+    outs.append(st.flush())
+    assert np.array_equal(np.concatenate(outs, axis=1), y_ref.numpy())
+    assert np.array_equal(st.phases()[1], s_ref.numpy())
+    # the increments themselves: a chain applied to frames 5.. of channels 3.. of a signal
+    ldk = (par.K + 1) & ~1
+    mag, inc = torch.zeros((c, 4, ldk), dtype=torch.float64), torch.zeros((c, 4, ldk), dtype=torch.float64)
+    _, got = filt.apply_dev(mag, inc, first_frame=5, first_channel=3)
+    exp = random_phase_expected(9, c, 4, par.K, position=0, first_frame=5, first_channel=3)
+    assert np.array_equal(got.numpy()[..., :par.K], exp)
+    assert not np.array_equal(exp[0, 0], exp[0, 1]) and not np.array_equal(exp[0, 0], exp[1, 0])

@@ -60,7 +60,7 @@ def main():
             for i, (lo, hi) in enumerate(T.pieces_of(par, sp, a.piece)):
                 pp = T._range_plan(par, sp.frames_total, lo, hi, False, False, hop)
                 mag, inc, carried = T.analyse(par, pp, source(pp.in_lo, pp.in_hi), carried)
-                mag, inc = T._filtered(filt, mag, inc)
+                mag, inc = T._filtered(filt, mag, inc, pp.f_lo)
                 par._call("voc_phase_advance_dev", C.c_void_p(inc.data_ptr()), inc.shape[2], inc.shape[1], inc.shape[0],
                           C.c_void_p(total.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
                 del mag, inc

@@ -16,7 +16,7 @@ import numpy as np
 from .vocoder import VocoderParams, _f64, _p, zero_phase
 
 __all__ = ["num_frames", "leftover_length", "ola_length", "frames_of_e", "sum_frames_e", "process_with",
-           "process", "process_dev", "roundtrip_workspace_bytes", "process_filter_dev", "deinterleave_dev", "interleave_dev", "pcm16_to_planar_dev", "planar_to_pcm16_dev"]
+           "process", "process_dev", "binary_frames_dev", "roundtrip_workspace_bytes", "process_filter_dev", "deinterleave_dev", "interleave_dev", "pcm16_to_planar_dev", "planar_to_pcm16_dev"]
 
 
 def num_frames(par: VocoderParams, length: int) -> int:
@@ -118,6 +118,24 @@ def process_dev(par: VocoderParams, x, y, ana_phase, syn_phase, length: int | No
     par._call("voc_roundtrip_f32_dev" if f32 else "voc_roundtrip_dev", C.c_void_p(x.data_ptr()), x.stride(0), length, c, chunk,
               C.c_void_p(y.data_ptr()), y.stride(0), C.c_void_p(ana_phase.data_ptr()),
               C.c_void_p(syn_phase.data_ptr()), lp, ls, wp, wb, C.c_void_p(st))
+
+
+def binary_frames_dev(par: VocoderParams, op: str, stft1, stft2):
+    """Two STFT streams combined element by element the way vocoder-jack's `--multiply`, `--divide`
+    and `--add` combine them (vocoder-dunai/example/VocoderJack.hs:107-110,127-135).  stft1, stft2:
+    (mag, ph_inc) pairs of equally shaped contiguous float64 device tensors; returns a new pair."""
+    import torch
+
+    code = {"multiply": 0, "divide": 1, "add": 2}[op]
+    (m1, i1), (m2, i2) = stft1, stft2
+    assert m1.shape == i1.shape == m2.shape == i2.shape and all(t.is_contiguous() for t in (m1, i1, m2, i2))
+    mo, io = torch.empty_like(m1), torch.empty_like(i1)
+    st = C.c_void_p(torch.cuda.current_stream(m1.device).cuda_stream) if m1.is_cuda else None
+    if m1.numel():
+        par._call("voc_binary_frames_dev", code, C.c_void_p(m1.data_ptr()), C.c_void_p(i1.data_ptr()),
+                  C.c_void_p(m2.data_ptr()), C.c_void_p(i2.data_ptr()), C.c_void_p(mo.data_ptr()),
+                  C.c_void_p(io.data_ptr()), m1.numel(), st)
+    return mo, io
 
 
 def process_filter_dev(par: VocoderParams, filt, x, length: int | None = None, chunk: int | None = None,

@@ -108,7 +108,8 @@ template <int LOG2M>
 __global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p, FilterProg prog,
                                                                         double *__restrict__ mag,
                                                                         double *__restrict__ inc, long long ldk,
-                                                                        long long rows, long long F, long long rpc)
+                                                                        long long rows, long long F, long long rpc,
+                                                                        long long first_frame, long long first_channel)
 {
     using Cf = FiltCfg<LOG2M>;
     constexpr int T = Cf::T, NE = Cf::NE;
@@ -190,17 +191,22 @@ __global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p
                 }
                 __syncthreads();
             } break;
-            case FOP_RANDOM_PHASE:  // randomPhaseFilter (Filter.hs:156-157): ph_inc uniform on [0, 2 pi)
+            case FOP_RANDOM_PHASE: {  // randomPhaseFilter (Filter.hs:156-157): ph_inc uniform on [0, 2 pi)
+                // The reference draws fresh numbers for every frame it is handed, however the frames are
+                // chunked.  The counter is therefore the frame's position in the whole signal, not in this
+                // call: (bin | position in the chain << 16, channel, frame low, frame high).
+                const unsigned long long chan = (unsigned long long)(first_channel + row / F);
+                const unsigned long long frame = (unsigned long long)(first_frame + row % F);
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
                     const int k = tid + T * j;
                     unsigned r0, r1;
-                    philox4x32_10((unsigned)k, (unsigned)row, (unsigned)((unsigned long long)row >> 32), (unsigned)o,
+                    philox4x32_10((unsigned)k | ((unsigned)o << 16), (unsigned)chan, (unsigned)frame, (unsigned)(frame >> 32),
                                   (unsigned)op.seed, (unsigned)(op.seed >> 32), &r0, &r1);
                     const unsigned long long bits = (((unsigned long long)r0 << 32) | r1) >> 11;
                     ic[j] = ((double)bits * 1.1102230246251565e-16) * kTwoPi;  // 53 random bits * 2^-53 * 2 pi
                 }
-                break;
+            } break;
             default: break;
             }
         }

@@ -1128,6 +1128,19 @@ __global__ void add_frames_kernel(const double *mag1, const double *inc1, const 
     }
 }
 
+// mkBinary op1 op2 (VocoderJack.hs:107-110): `--multiply` = (*) on the moduli, (+) on the increments;
+// `--divide` = (/) and (-)
+template <bool DIVIDE>
+__global__ void binary_frames_kernel(const double *mag1, const double *inc1, const double *mag2, const double *inc2,
+                                     double *mag_out, double *inc_out, long long total)
+{
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const double m1 = mag1[g], m2 = mag2[g], i1 = inc1[g], i2 = inc2[g];
+        mag_out[g] = DIVIDE ? m1 / m2 : m1 * m2;
+        inc_out[g] = DIVIDE ? i1 - i2 : i1 + i2;
+    }
+}
+
 // genFramesOfE on a whole buffer: frame j = x[j*H .. j*H + W)  (Frames.hs:34-35)
 __global__ void frames_of_kernel(const double *x, long long x_stride, double *frames, long long F, int W, int H,
                                  long long total)

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <optional>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -43,6 +44,12 @@ struct voc_ctx {
     voc::ParamsT<float> params_f{};
     void *ws = nullptr;
     size_t ws_bytes = 0;
+    // The library-owned workspace is shared by every call on the context, and _dev calls return
+    // after enqueueing: ws_event marks the end of the last enqueued use, and a call on another HIP
+    // stream waits for it before it touches the workspace.
+    hipEvent_t ws_event = nullptr;
+    hipStream_t ws_stream = nullptr;
+    bool ws_busy = false;
     int ana_tile_override = 0, syn_tile_override = 0, syn_slots_override = 0;
     bool force_generic = false;  // VOC_FORCE_GENERIC=1: never take the specialised kernels
 #ifndef VOC_EMU
@@ -378,6 +385,25 @@ void ensure_ws(voc_ctx *c, size_t bytes)
     c->ws_bytes = bytes;
 }
 
+// Brackets one enqueued use of the context's workspace on stream st (see voc_ctx::ws_event).
+struct WsUse {
+    voc_ctx *c;
+    hipStream_t st;
+    WsUse(voc_ctx *c_, hipStream_t st_) : c(c_), st(st_)
+    {
+        if (c->ws_busy && c->ws_stream != st) HIPCHK(hipStreamWaitEvent(st, c->ws_event, 0));
+    }
+    ~WsUse()
+    {
+        if (hipEventRecord(c->ws_event, st) == hipSuccess) {
+            c->ws_busy = true;
+            c->ws_stream = st;
+        }
+    }
+    WsUse(const WsUse &) = delete;
+    WsUse &operator=(const WsUse &) = delete;
+};
+
 inline long long num_frames(const voc_ctx *c, long long len) { return len < c->W ? 0 : (len - c->W) / c->H + 1; }
 
 inline long long ola_length(const voc_ctx *c, long long F, long long chunk)
@@ -401,6 +427,7 @@ void analysis_stage_dev(voc_ctx *c, double *phase_io, const double *frames, doub
                         long long F, hipStream_t st)
 {
     if (C <= 0 || F <= 0) return;
+    WsUse use(c, st);
     // the kernel reads the initial phases while another tile may already write the final ones
     ensure_ws(c, (size_t)C * c->K * sizeof(double));
     double *pin = static_cast<double *>(c->ws);
@@ -426,6 +453,7 @@ void synthesis_stage_dev(voc_ctx *c, double *phase_io, const double *mag, const 
                          long long C, long long F, hipStream_t st)
 {
     if (C <= 0 || F <= 0) return;
+    WsUse use(c, st);
     int tile_len, tiles;
     synthesis_tiling(c, C, F, 0, &tile_len, &tiles);
     const size_t pin_bytes = (size_t)C * c->K * sizeof(double);
@@ -464,6 +492,7 @@ void analysis_signal_dev(voc_ctx *c, const double *x, long long x_stride, long l
                          double *mag, double *inc, long long ldk, bool volume_fix, hipStream_t st, long long rpc = 0)
 {
     if (C <= 0 || F <= 0) return;
+    WsUse use(c, st);
     ensure_ws(c, (size_t)C * c->K * sizeof(double));
     double *pin = static_cast<double *>(c->ws);
     HIPCHK(hipMemcpyAsync(pin, phase_io, (size_t)C * c->K * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -495,6 +524,7 @@ void synthesis_signal_dev(voc_ctx *c, const double *mag, const double *inc, long
                           long long F_inc = 0)
 {
     if (C <= 0 || F <= 0) return;
+    WsUse use(c, st);
     const bool fused = !c->bluestein && lds_bytes(c, true) <= kLdsLimit;
     const int halo = fused ? (c->W + c->H - 1) / c->H - 1 : 0;
     int tile_len, tiles;
@@ -654,7 +684,9 @@ void roundtrip_dev(voc_ctx *c, const R *x, long long x_stride, long long len, lo
 
     // channels per pass: as many as the workspace holds
     long long group = C;
+    std::optional<WsUse> own;  // the library's own workspace is shared between calls; a caller's is the caller's to order
     if (!ws) {
+        own.emplace(c, st);
         size_t cap = (size_t)160 << 30;
         const int cap_gb = env_int("VOC_WS_CAP_GB");
         if (cap_gb > 0) cap = (size_t)cap_gb << 30;
@@ -789,6 +821,7 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return VOC_ERR_NO_DEVICE;
         if (device < 0 || device >= ndev) return VOC_ERR_INVALID;
         HIPCHK(hipSetDevice(device));
+        HIPCHK(hipEventCreateWithFlags(&c->ws_event, hipEventDisableTiming));
         c->N = N; c->W = W; c->H = H; c->K = N / 2 + 1; c->M = N / 2; c->device = device;
         c->bluestein = chirp;
         if (chirp) {  // the FFT underneath has L = 2^m >= 2N - 1 complex points
@@ -939,6 +972,7 @@ VOC_EXPORT int32_t voc_ctx_destroy(voc_ctx *c)
     if (!c) return VOC_OK;
     (void)hipSetDevice(c->device);
     if (c->ws) { (void)hipDeviceSynchronize(); (void)hipFree(c->ws); }
+    if (c->ws_event) (void)hipEventDestroy(c->ws_event);
     if (c->d_window) (void)hipFree(c->d_window);
     if (c->d_twP) (void)hipFree(c->d_twP);
     if (c->d_twS) (void)hipFree(c->d_twS);
@@ -1103,6 +1137,26 @@ VOC_EXPORT int32_t voc_add_frames_dev(voc_ctx *c, const double *mag1, const doub
         Locked lk(c);
         hipLaunchKernelGGL(voc::add_frames_kernel, dim3(ew_grid((long long)count)), dim3(256), 0, (hipStream_t)stream, mag1,
                            inc1, mag2, inc2, mag_out, inc_out, (long long)count);
+        HIPCHK(hipGetLastError());
+        return VOC_OK;
+    });
+}
+
+VOC_EXPORT int32_t voc_binary_frames_dev(voc_ctx *c, int32_t op, const double *mag1, const double *inc1, const double *mag2,
+                                         const double *inc2, double *mag_out, double *inc_out, int64_t count, void *stream)
+{
+    if (op == VOC_BINARY_ADD) return voc_add_frames_dev(c, mag1, inc1, mag2, inc2, mag_out, inc_out, count, stream);
+    if (op != VOC_BINARY_MULTIPLY && op != VOC_BINARY_DIVIDE) return VOC_ERR_INVALID;
+    if (!c || count < 0 || (count > 0 && (!mag1 || !inc1 || !mag2 || !inc2 || !mag_out || !inc_out))) return VOC_ERR_INVALID;
+    if (count == 0) return VOC_OK;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c);
+        if (op == VOC_BINARY_DIVIDE)
+            hipLaunchKernelGGL(voc::binary_frames_kernel<true>, dim3(ew_grid((long long)count)), dim3(256), 0,
+                               (hipStream_t)stream, mag1, inc1, mag2, inc2, mag_out, inc_out, (long long)count);
+        else
+            hipLaunchKernelGGL(voc::binary_frames_kernel<false>, dim3(ew_grid((long long)count)), dim3(256), 0,
+                               (hipStream_t)stream, mag1, inc1, mag2, inc2, mag_out, inc_out, (long long)count);
         HIPCHK(hipGetLastError());
         return VOC_OK;
     });

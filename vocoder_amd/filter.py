@@ -247,7 +247,12 @@ class BoundFilter:
                 m3, i3 = np.ascontiguousarray(m3[:, src]), np.ascontiguousarray(i3[:, src])
         return (m3, i3) if multi else (m3[0], i3[0])
 
-    def apply_dev_lazy(self, mag, ph_inc):
+    def _run_chain(self, chain, mag, ph_inc, ldk, f, c, st, first_frame, first_channel):
+        self.par.lib.check(self.par.lib.dll.voc_filter_apply_at_dev(
+            chain._h, C.c_void_p(mag.data_ptr()), C.c_void_p(ph_inc.data_ptr()), ldk, f, c, int(first_frame),
+            int(first_channel), st), self.par.handle)
+
+    def apply_dev_lazy(self, mag, ph_inc, first_frame: int = 0, first_channel: int = 0):
         """Like apply_dev, but a play_speed stage only composes a row map; an array is gathered
         only when a later chain reads it (a chain that overwrites ph_inc without reading it, like
         random_phase, gets a fresh array instead).  Returns (mag, mag_rows, ph_inc, inc_rows,
@@ -260,6 +265,8 @@ class BoundFilter:
         c, f, ldk = mag.shape
         for kind, v in self.parts:
             if kind == "speed":
+                if first_frame:
+                    raise ValueError("play_speed renumbers the frames: it cannot follow a frame offset")
                 src = torch.from_numpy(play_speed_map(self.par, v, f)).to(mag.device)
                 mrows = src if mrows is None else mrows[src]
                 irows = src if irows is None else irows[src]
@@ -270,7 +277,7 @@ class BoundFilter:
                     mag, mrows = mag.index_select(1, mrows), None
                 if irows is not None:
                     ph_inc, irows = ph_inc.index_select(1, irows), None
-                mag, ph_inc = self._apply_add(v, mag, ph_inc, st)
+                mag, ph_inc = self._apply_add(v, mag, ph_inc, st, first_frame, first_channel)
                 f = mag.shape[1]
                 continue
             flags = (C.c_int32 * 4)()
@@ -284,34 +291,36 @@ class BoundFilter:
                 elif store_inc:
                     ph_inc, irows = torch.empty((c, f, ldk), dtype=ph_inc.dtype, device=ph_inc.device), None
             if f and (load_mag or store_mag or load_inc or store_inc):
-                self.par.lib.check(self.par.lib.dll.voc_filter_apply_dev(
-                    v._h, C.c_void_p(mag.data_ptr()), C.c_void_p(ph_inc.data_ptr()), ldk, f, c, st), self.par.handle)
+                self._run_chain(v, mag, ph_inc, ldk, f, c, st, first_frame, first_channel)
         return mag, mrows, ph_inc, irows, f
 
-    def _apply_add(self, pair, mag, ph_inc, st):
+    def _apply_add(self, pair, mag, ph_inc, st, first_frame=0, first_channel=0):
         self.frames_out(mag.shape[1])
-        ma, ia = pair[0].apply_dev(mag.clone(), ph_inc.clone())
-        mag, ph_inc = pair[1].apply_dev(mag, ph_inc)
+        ma, ia = pair[0].apply_dev(mag.clone(), ph_inc.clone(), first_frame, first_channel)
+        mag, ph_inc = pair[1].apply_dev(mag, ph_inc, first_frame, first_channel)
         if mag.numel():
             self.par._call("voc_add_frames_dev", C.c_void_p(ma.data_ptr()), C.c_void_p(ia.data_ptr()),
                            C.c_void_p(mag.data_ptr()), C.c_void_p(ph_inc.data_ptr()), C.c_void_p(mag.data_ptr()),
                            C.c_void_p(ph_inc.data_ptr()), mag.numel(), st)
         return mag, ph_inc
 
-    def apply_dev(self, mag, ph_inc):
+    def apply_dev(self, mag, ph_inc, first_frame: int = 0, first_channel: int = 0):
         """torch tensors (C, F, ldk) in device memory: per-frame chains run in place; a play_speed
-        stage gathers into new tensors.  Returns the (mag, ph_inc) to hand to synthesis."""
+        stage gathers into new tensors.  Returns the (mag, ph_inc) to hand to synthesis.
+        first_frame / first_channel: where row 0 sits in the whole signal when the arrays hold a piece
+        of it (a run of a time-sharded segment, a block of channels); random_phase draws by position."""
         import torch
 
         st = C.c_void_p(torch.cuda.current_stream(mag.device).cuda_stream) if mag.is_cuda else None
         for kind, v in self.parts:
             c, f, ldk = mag.shape
             if kind == "chain":
-                self.par.lib.check(self.par.lib.dll.voc_filter_apply_dev(
-                    v._h, C.c_void_p(mag.data_ptr()), C.c_void_p(ph_inc.data_ptr()), ldk, f, c, st), self.par.handle)
+                self._run_chain(v, mag, ph_inc, ldk, f, c, st, first_frame, first_channel)
             elif kind == "add":
-                mag, ph_inc = self._apply_add(v, mag, ph_inc, st)
+                mag, ph_inc = self._apply_add(v, mag, ph_inc, st, first_frame, first_channel)
             else:
+                if first_frame:
+                    raise ValueError("play_speed renumbers the frames: it cannot follow a frame offset")
                 src = torch.from_numpy(play_speed_map(self.par, v, f)).to(mag.device)
                 fo = src.numel()
                 mo = torch.empty((c, fo, ldk), dtype=mag.dtype, device=mag.device)

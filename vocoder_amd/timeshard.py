@@ -235,16 +235,34 @@ def _zero_increments(filt) -> bool:
     return bool(filt is not None and getattr(filt, "zero_inc", False))
 
 
-def _filtered(filt, mag, inc):
+def _filtered(filt, mag, inc, first_frame: int = 0):
+    """The filter chain on a run of frames that starts at frame `first_frame` of the signal."""
     if filt is None:
         return mag, inc
     if filt.changes_frame_count:
         raise ValueError("play_speed changes the number of frames: it cannot run on a time-sharded signal")
-    return filt.apply_dev(mag, inc)
+    return filt.apply_dev(mag, inc, first_frame=first_frame)
+
+
+def _timed(stats, fn, device):
+    """Runs fn(); with a stats dict, brackets it with device synchronisation and adds the elapsed
+    seconds to stats["exchange_s"]."""
+    if stats is None:
+        return fn()
+    import time
+    import torch
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    out = fn()
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    stats["exchange_s"] = stats.get("exchange_s", 0.0) + time.perf_counter() - t0
+    return out
 
 
 def process_pieces(par, source, length: int, piece_frames: int, sink=None, filt=None, chunk: int | None = None,
-                   ana_phase=None, syn_phase=None, group=None):
+                   ana_phase=None, syn_phase=None, group=None, stats=None):
     """Time-sharded round trip of a signal too long to hold its STFT: every rank walks its segment
     in runs of about `piece_frames` frames, so device memory holds one run's samples and STFT.
 
@@ -262,6 +280,9 @@ def process_pieces(par, source, length: int, piece_frames: int, sink=None, filt=
     carried from run to run exactly as the reference carries them from frame to frame; overlap-add
     across a run boundary adds the older run's partial sums first (Frames.hs:52-58), which
     re-associates that sum of at most W/H terms by one rounding.
+
+    stats: an optional dict; the seconds spent in the two exchanges (all-gather, neighbour tails and
+    the final phase broadcast, device-synchronised on both sides) are added to stats["exchange_s"].
 
     Returns (y or None, (ana_phase', syn_phase')) — the phases after the signal's last frame, the
     same on every rank."""
@@ -294,7 +315,7 @@ def process_pieces(par, source, length: int, piece_frames: int, sink=None, filt=
         x = source(pp.in_lo, pp.in_hi)
         assert x.shape[1] == pp.in_hi - pp.in_lo, (x.shape, pp)
         mag, inc, ph = analyse(par, pp, x, carried)
-        mag, inc = _filtered(filt, mag, inc)
+        mag, inc = _filtered(filt, mag, inc, pp.f_lo)
         return pp, mag, inc, ph
 
     total = None
@@ -307,7 +328,7 @@ def process_pieces(par, source, length: int, piece_frames: int, sink=None, filt=
             par._call("voc_phase_advance_dev", _ptr(inc), inc.shape[2], inc.shape[1], inc.shape[0], _ptr(total),
                       _stream(inc))
         totals = [torch.empty_like(total) for _ in range(world)]
-        dist.all_gather(totals, total, group=group)
+        _timed(stats, lambda: dist.all_gather(totals, total, group=group), total.device)
     else:
         totals = None
 
@@ -347,7 +368,7 @@ def process_pieces(par, source, length: int, piece_frames: int, sink=None, filt=
         if prev_tail:
             tail_in = torch.empty_like(held)
             ops.append(dist.P2POp(dist.irecv, tail_in, dist.get_global_rank(group, rank - 1) if group else rank - 1, group))
-        _exchange(ops)
+        _timed(stats, lambda: _exchange(ops), carried.device)
         if tail_in is not None:
             held = tail_in + held
             if collected is not None:
@@ -355,7 +376,7 @@ def process_pieces(par, source, length: int, piece_frames: int, sink=None, filt=
             else:
                 sink(sp.out_lo, held)
         last = dist.get_global_rank(group, world - 1) if group else world - 1
-        dist.broadcast(carried, last, group=group)
-        dist.broadcast(sph, last, group=group)
+        _timed(stats, lambda: (dist.broadcast(carried, last, group=group), dist.broadcast(sph, last, group=group)),
+               carried.device)
     y_all = torch.cat(collected, dim=1) if collected is not None else None
     return y_all, (carried, sph)
