@@ -50,7 +50,8 @@ enum {
     VOC_ERR_HIP = -3,         /* a HIP runtime call failed; see voc_last_hip_error() */
     VOC_ERR_NOMEM = -4,       /* device or host allocation failed */
     VOC_ERR_SIZE = -5,        /* buffer / workspace too small, size mismatch (vector-fftw `execute`) */
-    VOC_ERR_NO_DEVICE = -6    /* no usable GPU */
+    VOC_ERR_NO_DEVICE = -6,   /* no usable GPU */
+    VOC_ERR_SCRATCH = -7      /* voc_roundtrip_static_dev: one channel needs more than VOC_STATIC_SCRATCH_BYTES */
 };
 
 /* VOC_PRECISION_F64: the reference's arithmetic; every entry point without `_f32` in its name.
@@ -188,6 +189,26 @@ int32_t voc_roundtrip_dev(voc_ctx *ctx, const double *x, int64_t x_stride, int64
                           int64_t chunk, double *y, int64_t y_stride, double *ana_phase_io, double *syn_phase_io,
                           double *leftover, int64_t leftover_stride, void *workspace, int64_t workspace_bytes,
                           void *stream);
+
+/* ---- fused round trip that allocates nothing ---------------------------------------------------
+ * voc_roundtrip_static_dev has no counterpart in the reference.  It is voc_roundtrip_dev for
+ * callers that cannot allocate device memory or let a library do so: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  The STFT, the phase snapshots
+ * and the tile carries of the call live in an array of VOC_STATIC_SCRATCH_BYTES that is part of
+ * the library's code object (one copy per GPU, held from the first context created on that GPU
+ * until the process ends); the call makes no hipMalloc / hipFree, creates no event and calls no
+ * allocating routine.  Same arguments, results and bits as voc_roundtrip_dev without its
+ * workspace pair.  Channels run in groups that fit the array; if ONE channel does not fit --
+ * voc_roundtrip_workspace_bytes(ctx, length, 1) > VOC_STATIC_SCRATCH_BYTES -- the call returns
+ * VOC_ERR_SCRATCH and touches nothing (N = 4096, H = 1024: about 2000 frames per channel,
+ * 43 s at 48 kHz).  Every call on one GPU, from any context or thread, uses that GPU's one
+ * array: calls that overlap in time on one GPU race; order them on one HIP stream or
+ * synchronise between them.  Nothing in the array has to be cleared between calls.
+ */
+#define VOC_STATIC_SCRATCH_BYTES (64u << 20)
+int32_t voc_roundtrip_static_dev(voc_ctx *ctx, const double *x, int64_t x_stride, int64_t length, int64_t channels,
+                                 int64_t chunk, double *y, int64_t y_stride, double *ana_phase_io,
+                                 double *syn_phase_io, double *leftover, int64_t leftover_stride, void *stream);
 
 /* ---- fused path, single precision (contexts created with VOC_PRECISION_F32) --------------------
  * Same contract as voc_roundtrip / voc_roundtrip_dev with float buffers; the phases returned

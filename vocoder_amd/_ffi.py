@@ -57,6 +57,7 @@ SIGNATURES = {
     "voc_filter_apply_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "voc_filter_apply_at_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp]),
     "voc_binary_frames_dev": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "voc_roundtrip_static_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "voc_play_speed_frames": (_i64, [_i64, _i64, _i64]),
     "voc_play_speed_map": (_i32, [_i64, _i64, _i64, _vp, _i64]),
     "voc_synthesis_mapped_dev": (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _vp]),

@@ -16,7 +16,7 @@ import numpy as np
 from .vocoder import VocoderParams, _f64, _p, zero_phase
 
 __all__ = ["num_frames", "leftover_length", "ola_length", "frames_of_e", "sum_frames_e", "process_with",
-           "process", "process_dev", "binary_frames_dev", "roundtrip_workspace_bytes", "process_filter_dev", "deinterleave_dev", "interleave_dev", "pcm16_to_planar_dev", "planar_to_pcm16_dev"]
+           "process", "process_dev", "process_static_dev", "binary_frames_dev", "roundtrip_workspace_bytes", "process_filter_dev", "deinterleave_dev", "interleave_dev", "pcm16_to_planar_dev", "planar_to_pcm16_dev"]
 
 
 def num_frames(par: VocoderParams, length: int) -> int:
@@ -118,6 +118,25 @@ def process_dev(par: VocoderParams, x, y, ana_phase, syn_phase, length: int | No
     par._call("voc_roundtrip_f32_dev" if f32 else "voc_roundtrip_dev", C.c_void_p(x.data_ptr()), x.stride(0), length, c, chunk,
               C.c_void_p(y.data_ptr()), y.stride(0), C.c_void_p(ana_phase.data_ptr()),
               C.c_void_p(syn_phase.data_ptr()), lp, ls, wp, wb, C.c_void_p(st))
+
+
+def process_static_dev(par: VocoderParams, x, y, ana_phase, syn_phase, length: int | None = None, chunk: int | None = None,
+                       leftover=None, stream=None):
+    """`process_dev` through the entry point that allocates nothing (voc_roundtrip_static_dev): the
+    STFT of the call lives in the library's static scratch array, so one channel of the input must
+    fit VOC_STATIC_SCRATCH_BYTES, and calls that overlap on one GPU race."""
+    import torch
+
+    assert x.is_cuda and y.is_cuda and x.dtype == torch.float64 and y.dtype == torch.float64
+    assert x.stride(-1) == 1 and y.stride(-1) == 1 and ana_phase.is_contiguous() and syn_phase.is_contiguous()
+    c = x.shape[0]
+    length = x.shape[1] if length is None else length
+    chunk = par.H if chunk is None else chunk
+    st = torch.cuda.current_stream(x.device).cuda_stream if stream is None else stream
+    lp, ls = (None, 0) if leftover is None else (C.c_void_p(leftover.data_ptr()), leftover.stride(0))
+    par._call("voc_roundtrip_static_dev", C.c_void_p(x.data_ptr()), x.stride(0), length, c, chunk,
+              C.c_void_p(y.data_ptr()), y.stride(0), C.c_void_p(ana_phase.data_ptr()),
+              C.c_void_p(syn_phase.data_ptr()), lp, ls, C.c_void_p(st))
 
 
 def binary_frames_dev(par: VocoderParams, op: str, stft1, stft2):

@@ -25,6 +25,17 @@
 
 #define VOC_EXPORT extern "C" __attribute__((visibility("default")))
 
+// Scratch of voc_roundtrip_static_dev: device memory that exists from the moment the code object is
+// loaded, one copy per GPU, held until the process ends.  In host code the array's name is only a
+// handle for hipGetSymbolAddress; the device address is looked up once per device (voc_ctx_create)
+// and kept in the context.
+constexpr size_t kStaticScratchBytes = (size_t)VOC_STATIC_SCRATCH_BYTES;
+#ifndef VOC_EMU
+static __device__ __align__(256) unsigned char voc_static_scratch[kStaticScratchBytes];
+#else
+alignas(256) static unsigned char voc_static_scratch[kStaticScratchBytes];
+#endif
+
 struct voc_ctx {
     int N = 0, W = 0, H = 0, K = 0, M = 0, log2m = 0, device = 0;
     std::vector<double> window;
@@ -50,6 +61,7 @@ struct voc_ctx {
     hipEvent_t ws_event = nullptr;
     hipStream_t ws_stream = nullptr;
     bool ws_busy = false;
+    void *static_scratch = nullptr;  // this device's copy of voc_static_scratch (allocation-free entry point)
     int ana_tile_override = 0, syn_tile_override = 0, syn_slots_override = 0;
     bool force_generic = false;  // VOC_FORCE_GENERIC=1: never take the specialised kernels
 #ifndef VOC_EMU
@@ -797,6 +809,7 @@ VOC_EXPORT const char *voc_strerror(int32_t s)
     case VOC_ERR_NOMEM: return "out of memory";
     case VOC_ERR_SIZE: return "size mismatch";
     case VOC_ERR_NO_DEVICE: return "no usable GPU";
+    case VOC_ERR_SCRATCH: return "one channel of this input needs more scratch than the library's static buffer holds";
     default: return "unknown status";
     }
 }
@@ -822,6 +835,9 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
         if (device < 0 || device >= ndev) return VOC_ERR_INVALID;
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipEventCreateWithFlags(&c->ws_event, hipEventDisableTiming));
+        // every GPU holds its own copy of the static scratch array at its own address: look it up with
+        // this context's device current and use only that pointer from here on
+        HIPCHK(hipGetSymbolAddress(&c->static_scratch, HIP_SYMBOL(voc_static_scratch)));
         c->N = N; c->W = W; c->H = H; c->K = N / 2 + 1; c->M = N / 2; c->device = device;
         c->bluestein = chirp;
         if (chirp) {  // the FFT underneath has L = 2^m >= 2N - 1 complex points
@@ -1299,6 +1315,39 @@ VOC_EXPORT int32_t voc_roundtrip_dev(voc_ctx *c, const double *x, int64_t x_stri
         Locked lk(c);
         roundtrip_dev(c, x, x_stride, len, C, chunk, y, y_stride, ana_phase_io, syn_phase_io, leftover,
                       leftover_stride, workspace, workspace_bytes, (hipStream_t)stream);
+        return VOC_OK;
+    });
+}
+
+// voc_roundtrip_dev on the library's static scratch array: no hipMalloc / hipFree, no allocating
+// library routine, no per-launch event.  Every call on one GPU shares that GPU's array.
+VOC_EXPORT int32_t voc_roundtrip_static_dev(voc_ctx *c, const double *x, int64_t x_stride, int64_t len, int64_t C,
+                                            int64_t chunk, double *y, int64_t y_stride, double *ana_phase_io,
+                                            double *syn_phase_io, double *leftover, int64_t leftover_stride, void *stream)
+{
+    if (!c || C < 0 || len < 0 || chunk < 1 || x_stride < len) return VOC_ERR_INVALID;
+    if (C == 0) return VOC_OK;
+    const long long F = num_frames(c, len);
+    if (!x || !ana_phase_io || !syn_phase_io) return VOC_ERR_INVALID;
+    if (F > 0 && (!y || y_stride < ola_length(c, F, chunk))) return VOC_ERR_SIZE;
+    if (leftover && leftover_stride < leftover_length(c, len)) return VOC_ERR_SIZE;
+    if (!c->static_scratch) return VOC_ERR_HIP;
+    // the channels run in groups that fit the array; one channel alone has to fit
+    if (roundtrip_plan(c, len, 1, chunk).per_channel_bytes > kStaticScratchBytes) return VOC_ERR_SCRATCH;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c);
+#ifndef VOC_EMU
+        struct NoEvents {  // launch timing creates events: off for the duration of this call
+            voc_ctx *c;
+            bool was;
+            explicit NoEvents(voc_ctx *c_) : c(c_), was(c_->profiling) { c->profiling = false; }
+            ~NoEvents() { c->profiling = was; }
+        } quiet(c);
+#endif
+        // nothing in the scratch layout (STFT rows, phase snapshots, tile carries) is read before this
+        // call has written it, so the previous call's contents need no clearing
+        roundtrip_dev(c, x, x_stride, len, C, chunk, y, y_stride, ana_phase_io, syn_phase_io, leftover,
+                      leftover_stride, c->static_scratch, (long long)kStaticScratchBytes, (hipStream_t)stream);
         return VOC_OK;
     });
 }
