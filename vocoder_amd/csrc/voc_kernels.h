@@ -228,12 +228,13 @@ VOC_DEV double approx_rcp(double b)
 #endif
 }
 
-// a / b for b in [2^-4, 2^4], |a| <= b (and a = 0 with any normal b > 0): hardware reciprocal seed, two Newton steps, one residual
-// correction of the quotient.
+// a / b for b in [2^-4, 2^4], |a| <= b (and a = 0 with any normal b > 0): hardware reciprocal seed
+// (relative error below 2^-24 on gfx950, measured over a dense sweep by tools/ubench/seed_precision.hip),
+// one Newton step (2^-48), one residual correction of the quotient -- on that sweep the bits of the
+// correctly rounded quotient.
 VOC_DEV double div_pos(double a, double b)
 {
     double r = approx_rcp(b);
-    r = fma(fma(-b, r, 1.0), r, r);
     r = fma(fma(-b, r, 1.0), r, r);
     const double q = a * r;
     return fma(fma(-b, q, a), r, q);
@@ -251,11 +252,12 @@ VOC_DEV int frexp_exponent(double v)  // exponent e with |v| = m 2^e, 0.5 <= m <
 }
 
 // sqrt(s) for s = 0 or 0.25 <= s < 2 (a sum of two squares of numbers scaled into [0, 1), the larger
-// one at least 0.5): reciprocal-square-root seed, one coupled Newton step on (sqrt, 1/(2 sqrt)), two
-// residual corrections -- the device library's own sequence without its rescaling of tiny
-// arguments and its special-case tests, neither of which can trigger on this domain.  For s = 0 the
-// seed is taken of a tiny positive number instead: it stays finite, every product with s is an
-// exact zero and the result is 0 without a test.
+// one at least 0.5): reciprocal-square-root seed (relative error below 2^-24 on gfx950), one coupled
+// Newton step on (sqrt, 1/(2 sqrt)), one residual correction -- the device library's own sequence
+// without its rescaling of tiny arguments, its special-case tests and its second correction, none
+// of which changes a bit on this domain (tools/ubench/seed_precision.hip).  For s = 0 the seed is taken of
+// a tiny positive number instead: it stays finite, every product with s is an exact zero and the
+// result is 0 without a test.
 VOC_DEV double sqrt_scaled(double s)
 {
 #ifdef VOC_EMU
@@ -267,7 +269,6 @@ VOC_DEV double sqrt_scaled(double s)
     const double r = fma(-h, g, 0.5);
     g = fma(g, r, g);
     h = fma(h, r, h);
-    g = fma(fma(-g, g, s), h, g);
     return fma(fma(-g, g, s), h, g);
 #endif
 }
@@ -313,31 +314,39 @@ VOC_DEV double atan_poly(double t)
 // power-of-two scaling commutes with every rounding, so the bits match the reference's whenever
 // its own intermediate squares neither overflow nor underflow.
 //
-// phase: 0 for 0:+0, else atan2 y x in (-pi, pi] with atan2(+-0, x<0) = +-pi, as GHC's and
-// IEEE's.  q = min/max of the magnitudes is folded once, atan q = pi/4 + atan((q-1)/(q+1)) for
-// q > tan(pi/8), BEFORE the one division; then the octant is undone.  Finite inputs only: an
-// infinite or NaN component gives NaN.
+// phase: 0 for 0:+0, else atan2 y x in (-pi, pi] with atan2(+-0, x<0) = +-pi, as GHC's and IEEE's.
+// The angle phi of (|x|, |y|) in [0, pi/2] comes from its half: tan(phi/2) = |y| / (r + |x|) with the
+// r = sqrt(x^2 + y^2) the magnitude already needs, a quotient in [0, 1] -- so there is no swap of the
+// two components and no octant to undo.  The quotient is folded once at tan(pi/8),
+// atan t = pi/4 + atan((t-1)/(t+1)), BEFORE the one division.  Every case distinction is arithmetic
+// on a 0.0 / 1.0 or +-2.0 factor (one 32-bit select each: only the high word of such a constant
+// varies) instead of a select between two doubles:
+//   f  = 1 when folded:      num = |y| - f (r+|x|),  den = (r+|x|) + f |y|,  phi/2 = atan(num/den) + f pi/4
+//   s2 = -2 for x < 0, else 2:   atan2(|y|, x) = s2 phi/2 + (pi/2 - s2 pi/4)        [= phi or pi - phi]
+// (f = 0 and s2 = 2 reproduce the plain values exactly: the products are exact and the added zero
+// changes nothing), then the sign of y.  Accurate to about an ulp like the direct form; an exactly
+// real or imaginary bin still gives exactly 0, +-pi/2 or +-pi.  Finite inputs only: an infinite or
+// NaN component gives NaN.
 //
-// The zero bin needs no test of its own (a test the compiler turns into a branch around half of
-// the function, which keeps it from interleaving the chains of two bins): its divisor is replaced
-// by a tiny positive number, so q = 0, atan q = 0, and "x negative" is decided by x < 0, false for
-// -0.  The result is a zero with the sign of y (the reference's is +0 for every zero bin).
+// The zero bin needs no test of its own: its divisor is replaced by a tiny positive number, so the
+// quotient is 0, and "x negative" is decided by x < 0, false for -0.  The result is a zero with the
+// sign of y (the reference's is +0 for every zero bin).
 VOC_DEV void hs_polar(double x, double y, double &mag, double &ph)
 {
     const double ax = fabs(x), ay = fabs(y);
     const int e = frexp_exponent(fmax(ax, ay));
     const double sx = ldexp(ax, -e), sy = ldexp(ay, -e);
     const double a = sx * sx, b = sy * sy;
-    mag = ldexp(sqrt_scaled(a + b), e);
-    const double mx = fmax(sx, sy), mn = fmin(sx, sy);
-    const bool fold = mn > 0.41421356237309503 * mx;
-    const double num = fold ? mn - mx : mn;
-    const double den = fmax(fold ? mn + mx : mx, 0x1p-1000);  // in [0.5, 2) unless the bin is zero
-    double t = atan_poly(div_pos(num, den));
-    t = fold ? t + 0.78539816339744828 : t;
-    t = (ay > ax) ? 1.5707963267948966 - t : t;
-    t = (x < 0.0) ? kPi - t : t;
-    ph = copysign(t, y);
+    const double r = sqrt_scaled(a + b);  // in [0.5, 1.42), or 0
+    mag = ldexp(r, e);
+    const double d0 = r + sx;             // in [0.5, 2.42), or 0
+    const double f = (sy > 0.41421356237309503 * d0) ? 1.0 : 0.0;
+    const double num = fma(-f, d0, sy);
+    const double den = fmax(fma(f, sy, d0), 0x1p-1000);  // in [0.5, 3.84) unless the bin is zero
+    const double half = fma(f, 0.78539816339744828, atan_poly(div_pos(num, den)));
+    const double s2 = (x < 0.0) ? -2.0 : 2.0;
+    const double off = fma(-s2, 0.78539816339744828, 1.5707963267948966);  // 0 or pi, exactly
+    ph = copysign(fma(s2, half, off), y);
 }
 
 VOC_DEV double hs_magnitude(double x, double y)
@@ -411,16 +420,19 @@ VOC_DEV void fast_sincos(double x, double *sn, double *cs)
 }
 
 // wrap e = (e + pi) `mod'` (2 pi) - pi with mod' n d = n - floor(n/d) * d and the floor taken
-// of the exact quotient (Vocoder.hs:166-167, Data.Fixed).  The exact floor is recovered from
-// an approximate quotient through the sign of the exactly rounded remainder.
+// of the exact quotient (Vocoder.hs:166-167, Data.Fixed).  The floor f0 of the rounded quotient is
+// the exact floor or one off; the remainder r0 = n - f0 * 2pi (one fma: exactly rounded, so its sign
+// and its comparison with 2 pi are those of the exact remainder unless it lies within half an ulp
+// of 2 pi) then falls in [-2pi, 0) or [2pi, 4pi) instead of [0, 2pi), and floor(r0 / 2pi) is the
+// correction -- no compare, no select.  Only a remainder within an ulp of 2 pi (probability
+// ~2^-52 per call) can still be taken for a full turn: the result is then one turn off, i.e. -pi - tiny
+// instead of pi - tiny, the same angle.
 VOC_DEV double hs_wrap(double e)
 {
     const double n = e + kPi;
     const double f0 = floor(n * kInvTwoPi);
-    const double fm = f0 - 1.0, fp = f0 + 1.0;
-    const bool below = fma(-f0, kTwoPi, n) < 0.0;   // exact sign of n - f0*2pi
-    const bool above = fma(-fp, kTwoPi, n) >= 0.0;  // exact sign of n - (f0+1)*2pi
-    const double f = below ? fm : (above ? fp : f0);
+    const double r0 = fma(-f0, kTwoPi, n);
+    const double f = f0 + floor(r0 * kInvTwoPi);
     const double t = f * kTwoPi;
     return (n - t) - kPi;
 }

@@ -365,13 +365,33 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
 
         const long long row = c * a.rpc + f;
         R *mrow = a.mag + row * a.ldk, *irow = a.inc + row * a.ldk;
-VOC_UNROLL(VOC_POLAR_UNROLL)
+        // Thread t owns the bin pairs (t + mT, M - t - mT), m = 0..3; thread 0's first pair is the
+        // self-paired bin M/2.  The loop is unrolled so that m is a constant in every copy: the LDS
+        // addresses of a pair are then one per-thread base plus an immediate (element e lives at
+        // e + e/8 and T is a multiple of 8, so both bases move by whole multiples of T + T/8), the split
+        // twiddle's rotation is a literal, and the self-pair case exists in the first copy only.  A
+        // scheduling fence after every copy keeps their live ranges apart (the register budget is
+        // that of one pair).
+        const int lt = opaque_int(tid);
+        const bool self0 = lt == 0;
+        const unsigned pe0 = self0 ? M / 2 : (unsigned)lt;      // first pair: bins pe0 and M - pe0
+        const C2 *zlo = lds + lds_pad(lt), *zhi = lds + lds_pad(M - lt);
+#pragma unroll
         for (int m = 0; m < 4; ++m) {
-            const unsigned pr = tid + m * T;
-            const unsigned pe = pr == 0 ? M / 2 : pr;
+            const unsigned pe = m == 0 ? pe0 : (unsigned)(lt + m * T);
             const unsigned q = M - pe;
+            C2 P, Q, w;
+            if (m == 0) {
+                P = lds[lds_pad(pe)];
+                Q = lds[lds_pad(q)];
+                w = split_tw(tw.s, 0, self0);
+            } else {
+                P = zlo[m * (T + T / 8)];
+                Q = zhi[-m * (T + T / 8)];
+                w = split_tw(tw.s, m, false);
+            }
             C2 Xa, Xb;
-            split_pair_x2(lds[lds_pad(pe)], lds[lds_pad(q)], split_tw(tw.s, m, pr == 0), Xa, Xb);
+            split_pair_x2(P, Q, w, Xa, Xb);
             const R pa = php[pe], pb = php[q];
             R ma, mb, pha, phb;
             hs_polar(Xa.x, Xa.y, ma, pha);
@@ -389,6 +409,7 @@ VOC_UNROLL(VOC_POLAR_UNROLL)
             }
             php[pe] = pha;
             php[q] = phb;
+            sched_fence();
         }
         // DC and Nyquist bins are real: phase 0 or pi, magnitude |x|.  Two different waves take one
         // each, so that no wave (and no SIMD) carries both on top of its four bin pairs.

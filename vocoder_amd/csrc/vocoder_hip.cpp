@@ -165,8 +165,13 @@ template <class R> const voc::ParamsT<R> &params_of(const voc_ctx *c);
 template <> const voc::ParamsT<double> &params_of<double>(const voc_ctx *c) { return c->params; }
 template <> const voc::ParamsT<float> &params_of<float>(const voc_ctx *c) { return c->params_f; }
 
+#ifdef VOC_DEV_ONLY_LOG2M  // development builds for timing experiments: one frame length only, compiled in seconds
+#define VOC_FOR_EACH_LOG2M(X) X(VOC_DEV_ONLY_LOG2M)
+#define VOC_FOR_EACH_BLUE_LOG2L(X) X(VOC_DEV_ONLY_LOG2M)
+#else
 #define VOC_FOR_EACH_LOG2M(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
 #define VOC_FOR_EACH_BLUE_LOG2L(X) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
+#endif
 
 template <bool RAW, bool SPEC, class R = double>
 void launch_analysis(voc_ctx *c, const voc::AnaArgsT<R> &a, long long channels, hipStream_t st)
@@ -240,7 +245,11 @@ void launch_synthesis(voc_ctx *c, const voc::SynArgsT<R> &a, long long channels,
     HIPCHK(hipGetLastError());
 }
 
+#ifdef VOC_DEV_ONLY_LOG2M
+#define VOC_FOR_EACH_FAST_LOG2M(X) X(VOC_DEV_ONLY_LOG2M)
+#else
 #define VOC_FOR_EACH_FAST_LOG2M(X) X(9) X(10) X(11) X(12)
+#endif
 
 inline bool fast_sizes(const voc_ctx *c) { return !c->force_generic && !c->bluestein && c->log2m >= 9 && c->log2m <= 12; }
 
