@@ -366,25 +366,20 @@ VOC_DEV double hs_phase(double x, double y)
 // sin and cos of an UNWRAPPED phase: n = round(x 2/pi) by the 1.5*2^52 trick, two-step Cody-Waite
 // reduction with fma (x - n*hi is exact: both are multiples of 2^-52 and the difference is below
 // 1), then the classical degree-13 / degree-14 kernels on [-pi/4, pi/4].  Accurate to about an ulp
-// for |x| < 2^50 (a phase that large has a resolution of 0.25 rad; beyond it, and for inf / nan,
-// the result is NaN).
+// for |x| < 2^50 (a phase that large has a resolution of 0.25 rad).
 //
-// LEAN gives the same bits with fewer instructions and no branch: the out-of-range NaN is made by
-// replacing the high word alone (the division of the plain form is compiled as a branch around it,
-// once per bin), and the quadrant signs are bit 1 of q (of q + 1) moved onto the sign bit instead of
-// two negate-and-select pairs.  Without the branches the bins of a loop body become one scheduling
-// region; where registers are scarce that region is scheduled worse than the separate ones, so the
-// caller chooses (the specialised synthesis kernel: lean from N = 2048 up).
+// The plain form returns NaN beyond 2^50 and for inf / nan.  LEAN gives the same bits on the valid
+// range with fewer instructions and no branch: there is no range test (inf and nan still come out
+// as NaN through the reduction, a finite phase beyond 2^50 gives some finite value of no
+// meaning -- at 1024 samples a hop that takes 10^9 hours of audio), the quadrant's parity is one
+// 32-bit test, and the quadrant signs are bits of q moved onto the sign bits (sine: bit 1; cosine:
+// bit 1 xor bit 0) instead of two negate-and-select pairs.  Without the branches the bins of a
+// loop body become one scheduling region; where registers are scarce that region is scheduled worse
+// than the separate ones, so the caller chooses (the specialised synthesis kernel: lean from N = 2048 up).
 template <bool LEAN = false>
 VOC_DEV void fast_sincos(double x, double *sn, double *cs)
 {
-    if (LEAN) {
-        const unsigned long long xb = __builtin_bit_cast(unsigned long long, x);
-        const unsigned hi = (fabs(x) < 0x1p50) ? (unsigned)(xb >> 32) : 0x7ff80000u;
-        x = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (xb & 0xffffffffull));
-    } else {
-        x = (fabs(x) < 0x1p50) ? x : (x - x) / (x - x);
-    }
+    if (!LEAN) x = (fabs(x) < 0x1p50) ? x : (x - x) / (x - x);
     const double big = 0x1.8p52;
     const double tn = fma(x, 0.63661977236758138, big);
     const double n = tn - big;
@@ -406,13 +401,16 @@ VOC_DEV void fast_sincos(double x, double *sn, double *cs)
     pc = fma(pc, z, -1.38888888888741095749e-03);
     pc = fma(pc, z, 4.16666666666666019037e-02);
     const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
-    const double s1 = (q & 1u) ? c : s;
-    const double c1 = (q & 1u) ? s : c;
+    const bool odd = (q & 1u) != 0u;
+    const double s1 = odd ? c : s;
+    const double c1 = odd ? s : c;
     if (LEAN) {  // quadrants 2, 3 negate the sine, 1, 2 the cosine
-        const unsigned long long fs = (unsigned long long)((q << 30) & 0x80000000u) << 32;
-        const unsigned long long fc = (unsigned long long)(((q + 1u) << 30) & 0x80000000u) << 32;
-        *sn = __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, s1) ^ fs);
-        *cs = __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, c1) ^ fc);
+        const unsigned long long s1b = __builtin_bit_cast(unsigned long long, s1), c1b = __builtin_bit_cast(unsigned long long, c1);
+        const unsigned fs = (q << 30) & 0x80000000u;  // bit 1 of q
+        const unsigned f1 = q << 31;                  // bit 0 of q
+        const unsigned shi = (unsigned)(s1b >> 32) ^ fs, chi = ((unsigned)(c1b >> 32) ^ fs) ^ f1;
+        *sn = __builtin_bit_cast(double, ((unsigned long long)shi << 32) | (s1b & 0xffffffffull));
+        *cs = __builtin_bit_cast(double, ((unsigned long long)chi << 32) | (c1b & 0xffffffffull));
     } else {
         *sn = (q & 2u) ? -s1 : s1;
         *cs = ((q + 1u) & 2u) ? -c1 : c1;

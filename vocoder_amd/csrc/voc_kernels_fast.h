@@ -127,6 +127,20 @@ VOC_DEV void sched_fence()
 #endif
 }
 
+// base[byte_off + imm]: a uniform base pointer, a 32-bit per-lane byte offset and a small constant --
+// the shape the hardware addresses in one instruction (scalar base + vector offset + immediate), spelled
+// out so that the compiler does not rebuild a 64-bit address per access
+template <class R>
+VOC_DEV const R &at_bytes(const R *base, unsigned byte_off, int imm)
+{
+    return *reinterpret_cast<const R *>(reinterpret_cast<const char *>(base) + ((size_t)byte_off + (long long)imm));
+}
+template <class R>
+VOC_DEV R &at_bytes(R *base, unsigned byte_off, int imm)
+{
+    return *reinterpret_cast<R *>(reinterpret_cast<char *>(base) + ((size_t)byte_off + (long long)imm));
+}
+
 template <class C2>
 VOC_DEV C2 csqr(C2 a) { return mk2(fma(a.x, a.x, -(a.y * a.y)), (a.x + a.x) * a.y); }
 
@@ -376,10 +390,17 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
         const bool self0 = lt == 0;
         const unsigned pe0 = self0 ? M / 2 : (unsigned)lt;      // first pair: bins pe0 and M - pe0
         const C2 *zlo = lds + lds_pad(lt), *zhi = lds + lds_pad(M - lt);
+        // byte offsets of the pair's bins in an STFT row and in the phase array: slot 0 has its own, slots
+        // 1..3 sit at +-(m - 2) T elements around one offset each (immediates of the memory instructions)
+        constexpr int SZ = (int)sizeof(R);
+        const unsigned o_pe0 = pe0 * SZ, o_q0 = (unsigned)(M * SZ) - o_pe0;
+        const unsigned o_pe2 = (unsigned)(lt + 2 * T) * SZ, o_q2 = (unsigned)(M * SZ) - o_pe2;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const unsigned pe = m == 0 ? pe0 : (unsigned)(lt + m * T);
             const unsigned q = M - pe;
+            const unsigned ope = m == 0 ? o_pe0 : o_pe2, oq = m == 0 ? o_q0 : o_q2;
+            const int ipe = m == 0 ? 0 : (m - 2) * T * SZ, iq = -ipe;
             C2 P, Q, w;
             if (m == 0) {
                 P = lds[lds_pad(pe)];
@@ -392,23 +413,23 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
             }
             C2 Xa, Xb;
             split_pair_x2(P, Q, w, Xa, Xb);
-            const R pa = php[pe], pb = php[q];
+            const R pa = at_bytes(php, ope, ipe), pb = at_bytes(php, oq, iq);
             R ma, mb, pha, phb;
             hs_polar(Xa.x, Xa.y, ma, pha);
             hs_polar(Xb.x, Xb.y, mb, phb);
             if (emit) {
-                mrow[pe] = ma * half_vol;
-                mrow[q] = mb * half_vol;
+                at_bytes(mrow, ope, ipe) = ma * half_vol;
+                at_bytes(mrow, oq, iq) = mb * half_vol;
                 if constexpr (SLIDE > 0) {  // H = SLIDE * N/8: a power of two, like N
-                    irow[pe] = phase_inc_pow2(p, pe, pha - pa);
-                    irow[q] = phase_inc_pow2(p, q, phb - pb);
+                    at_bytes(irow, ope, ipe) = phase_inc_pow2(p, pe, pha - pa);
+                    at_bytes(irow, oq, iq) = phase_inc_pow2(p, q, phb - pb);
                 } else {
-                    irow[pe] = phase_inc(p, pe, pha - pa);
-                    irow[q] = phase_inc(p, q, phb - pb);
+                    at_bytes(irow, ope, ipe) = phase_inc(p, pe, pha - pa);
+                    at_bytes(irow, oq, iq) = phase_inc(p, q, phb - pb);
                 }
             }
-            php[pe] = pha;
-            php[q] = phb;
+            at_bytes(php, ope, ipe) = pha;
+            at_bytes(php, oq, iq) = phb;
             sched_fence();
         }
         // DC and Nyquist bins are real: phase 0 or pi, magnitude |x|.  Two different waves take one
@@ -505,18 +526,25 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
 
     // STFT row of frame f: (mag, ph_inc) of this thread's eight bins, plus DC / Nyquist for thread 0
     R mg[8], ic[8], mg0 = (R)0, mgm = (R)0, ic0 = (R)0, icm = (R)0;
-    auto load_row = [&](long long f, int lt) {
+    // Bins of pair slot m: pe = tid + m T (thread 0, slot 0: the self-paired bin M/2) and q = M - pe.  Their
+    // byte offsets in a row are four per-thread values plus immediates: slot 0 has its own pair of
+    // offsets, slots 1..3 sit at +-(m - 2) T elements around one offset each.
+    constexpr int SZ = (int)sizeof(R);
+    const unsigned row_pe0 = (unsigned)(tid == 0 ? M / 2 : tid) * SZ, row_q0 = (unsigned)(M * SZ) - row_pe0;
+    const unsigned row_pe2 = (unsigned)(tid + 2 * T) * SZ, row_q2 = (unsigned)(M * SZ) - row_pe2;
+    auto load_row = [&](long long f, int) {
         const R *mrow = MAPPED ? mag_row_of(a, c, f) : a.mag + (c * a.F + f) * a.ldk;
         const R *irow = MAPPED ? inc_row_of(a, c, f) : a.inc + (c * a.F + f) * a.ldk;
+        mg[0] = at_bytes(mrow, row_pe0, 0);
+        ic[0] = at_bytes(irow, row_pe0, 0);
+        mg[1] = at_bytes(mrow, row_q0, 0);
+        ic[1] = at_bytes(irow, row_q0, 0);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const unsigned pr = lt + m * T;
-            const unsigned pe = pr == 0 ? M / 2 : pr;
-            const unsigned q = M - pe;
-            mg[2 * m] = mrow[pe];
-            ic[2 * m] = irow[pe];
-            mg[2 * m + 1] = mrow[q];
-            ic[2 * m + 1] = irow[q];
+        for (int m = 1; m < 4; ++m) {
+            mg[2 * m] = at_bytes(mrow, row_pe2, (m - 2) * T * SZ);
+            ic[2 * m] = at_bytes(irow, row_pe2, (m - 2) * T * SZ);
+            mg[2 * m + 1] = at_bytes(mrow, row_q2, (2 - m) * T * SZ);
+            ic[2 * m + 1] = at_bytes(irow, row_q2, (2 - m) * T * SZ);
         }
         if (tid == 0) {
             mg0 = mrow[0];
