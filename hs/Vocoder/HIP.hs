@@ -2,8 +2,9 @@
 Module      : Vocoder.HIP
 Description : The @Vocoder@ core API on top of libvocoder_hip.so
 
-Drop-in definitions for the part of vocoder/src/Vocoder.hs that touches the FFT binding.  Types
-and names are the reference's (Vocoder.hs:54-111); only their bodies change:
+Drop-in for vocoder/src/Vocoder.hs: every name of its export list (Vocoder.hs:12-42) is exported
+here with the reference's type, so a package that says @import Vocoder@ builds against this module
+renamed (or re-exported) as @Vocoder@.  Only the bodies change:
 
   * 'VocoderParams' holds a 'ForeignPtr' to the library context instead of two FFTW plans
     (Vocoder.hs:89-99); 'vocoderParams' has the same signature (Vocoder.hs:114-115).
@@ -13,18 +14,28 @@ and names are the reference's (Vocoder.hs:54-111); only their bodies change:
   * a non-zero status becomes 'error', as the reference does for bad sizes (Vocoder.hs:132) and as
     vector-fftw's @execute@ does for a length mismatch.
 
-vocoder-conduit and vocoder-dunai need no source change: they only use the names re-exported here
+  * 'doFFT' / 'doIFFT' (Vocoder.hs:143-145,194-196) are one-frame calls on the context;
+    'analysisStep', 'synthesisStep', 'frameFromComplex', 'frameToComplex' and 'addFrames'
+    (Vocoder.hs:158,186,213,217,221) take no 'VocoderParams' in the reference and none here: they
+    bind the entry points of the library that need no context.
+
+vocoder-conduit and vocoder-dunai need no source change: they only use names exported here
 (Conduit.hs:39,43,64,68; Dunai.hs:30,34).  Could not be compiled where it was written (no GHC).
 -}
 module Vocoder.HIP
-    ( VocoderParams, vocoderParams, vocFrameLength, vocInputFrameLength, vocFreqFrameLength
-    , vocHopSize, vocWindow, analysisStage, analysisBlock, synthesisStage, synthesisBlock
-    , zeroPhase, volumeCoeff, addFrames, processChannels
-    , Moduli, Phase, PhaseInc, Frame, Window, STFTFrame
-    , vocCtx, check   -- for the sibling modules Vocoder.HIP.Filter
+    ( -- the export list of Vocoder.hs:12-42, in its order
+      Moduli, Phase, PhaseInc, Frame, Window, HopSize, Length, STFTFrame, FFTOutput
+    , VocoderParams, vocoderParams, vocFrameLength, vocInputFrameLength, vocFreqFrameLength
+    , vocHopSize, vocWindow, doFFT, doIFFT, analysisBlock, analysisStep, analysisStage
+    , synthesisBlock, synthesisStep, synthesisStage, zeroPhase, volumeCoeff
+    , frameFromComplex, frameToComplex, addFrames
+      -- beyond the reference: the fused round trip on whole channels
+    , processChannels
+    , vocCtx, check   -- for the sibling modules Vocoder.HIP.Filter and Vocoder.HIP.Conduit
     ) where
 
 import Control.Monad (when)
+import Data.Complex (Complex)
 import Data.Int (Int32)
 import Data.Foldable (toList)
 import Data.Traversable (mapAccumL)
@@ -43,7 +54,10 @@ type Phase = V.Vector Double
 type PhaseInc = V.Vector Double
 type Frame = V.Vector Double
 type Window = Frame
+type HopSize = Int
+type Length = Int
 type STFTFrame = (Moduli, PhaseInc)
+type FFTOutput = V.Vector (Complex Double)
 
 data VocoderParams = VocoderParams
     { vocCtx :: ForeignPtr VocCtx
@@ -81,6 +95,72 @@ zeroPhase par = V.replicate (vocFreqFrameLength par) 0
 
 volumeCoeff :: VocoderParams -> Double
 volumeCoeff par = unsafePerformIO $ withForeignPtr (vocCtx par) c_voc_volume_coeff
+
+-- | doFFT (Vocoder.hs:143-145): window, zero padding, rewind, real-to-complex transform.
+doFFT :: VocoderParams -> Frame -> FFTOutput
+doFFT par fr = unsafePerformIO $ do
+    when (V.length fr /= vocInputFrameLength par) $ error "doFFT: frame length mismatch"
+    out <- MV.new (2 * vocFreqFrameLength par)
+    withForeignPtr (vocCtx par) $ \ctx -> V.unsafeWith fr $ \pf -> MV.unsafeWith out $ \po ->
+        check "doFFT" $ c_voc_do_fft ctx pf po 1
+    V.unsafeCast <$> V.unsafeFreeze out
+
+-- | doIFFT (Vocoder.hs:194-196): complex-to-real transform, rewind, cutCenter, window.
+doIFFT :: VocoderParams -> FFTOutput -> Frame
+doIFFT par spec = unsafePerformIO $ do
+    when (V.length spec /= vocFreqFrameLength par) $ error "doIFFT: spectrum length mismatch"
+    out <- MV.new (vocInputFrameLength par)
+    withForeignPtr (vocCtx par) $ \ctx -> V.unsafeWith (V.unsafeCast spec) $ \ps -> MV.unsafeWith out $ \po ->
+        check "doIFFT" $ c_voc_do_ifft ctx ps po 1
+    V.unsafeFreeze out
+
+-- | analysisStep h eN prev_ph vec (Vocoder.hs:158-163).  The two vectors have one length in every
+--   use of the reference; if they differ, all three results are cut to the shorter (the reference
+--   cuts only ph_inc, through its zipWith).
+analysisStep :: HopSize -> Length -> Phase -> FFTOutput -> (Phase, STFTFrame)
+analysisStep h eN prev_ph vec = unsafePerformIO $ do
+    let k = min (V.length prev_ph) (V.length vec)
+    ph <- MV.new k
+    mag <- MV.new k
+    inc <- MV.new k
+    V.unsafeWith prev_ph $ \pp -> V.unsafeWith (V.unsafeCast vec) $ \pv ->
+        MV.unsafeWith ph $ \po -> MV.unsafeWith mag $ \pm -> MV.unsafeWith inc $ \pin ->
+            check "analysisStep" $
+                c_voc_analysis_step_hn (fromIntegral h) (fromIntegral eN) (fromIntegral k) pp pv po pm pin 1
+    phv <- V.unsafeFreeze ph
+    magv <- V.unsafeFreeze mag
+    incv <- V.unsafeFreeze inc
+    return (phv, (magv, incv))
+
+-- | synthesisStep hop ph (mag, ph_inc) (Vocoder.hs:186-190)
+synthesisStep :: HopSize -> Phase -> STFTFrame -> (Phase, FFTOutput)
+synthesisStep hop ph (mag, ph_inc) = unsafePerformIO $ do
+    let k = minimum [V.length ph, V.length mag, V.length ph_inc]
+    new_ph <- MV.new k
+    spec <- MV.new (2 * k)
+    V.unsafeWith ph $ \pp -> V.unsafeWith mag $ \pm -> V.unsafeWith ph_inc $ \pin ->
+        MV.unsafeWith new_ph $ \po -> MV.unsafeWith spec $ \ps ->
+            check "synthesisStep" $ c_voc_synthesis_step_h (fromIntegral hop) (fromIntegral k) pp pm pin po ps 1
+    (,) <$> V.unsafeFreeze new_ph <*> (V.unsafeCast <$> V.unsafeFreeze spec)
+
+-- | frameFromComplex (Vocoder.hs:217-218)
+frameFromComplex :: FFTOutput -> STFTFrame
+frameFromComplex vec = unsafePerformIO $ do
+    let k = V.length vec
+    mag <- MV.new k
+    ph <- MV.new k
+    V.unsafeWith (V.unsafeCast vec) $ \pv -> MV.unsafeWith mag $ \pm -> MV.unsafeWith ph $ \pp ->
+        check "frameFromComplex" $ c_voc_frame_from_complex pv pm pp (fromIntegral k)
+    (,) <$> V.unsafeFreeze mag <*> V.unsafeFreeze ph
+
+-- | frameToComplex (Vocoder.hs:213-214)
+frameToComplex :: STFTFrame -> FFTOutput
+frameToComplex (mag, ph) = unsafePerformIO $ do
+    let k = min (V.length mag) (V.length ph)
+    spec <- MV.new (2 * k)
+    V.unsafeWith mag $ \pm -> V.unsafeWith ph $ \pp -> MV.unsafeWith spec $ \ps ->
+        check "frameToComplex" $ c_voc_frame_to_complex pm pp ps (fromIntegral k)
+    V.unsafeCast <$> V.unsafeFreeze spec
 
 -- | analysisStage (Vocoder.hs:149-150): one FFI call for the whole container of frames.
 analysisStage :: Traversable t => VocoderParams -> Phase -> t Frame -> (Phase, t STFTFrame)
@@ -154,14 +234,12 @@ processChannels par chunk xs (aphs, sphs) = unsafePerformIO $ do
         return (rows ol yv, rows keep lv, (rows k av, rows k sv))
 
 -- | Adds STFT frames (Vocoder.hs:220-222): polar to complex, sum, complex to polar, on the device.
-addFrames :: VocoderParams -> STFTFrame -> STFTFrame -> STFTFrame
-addFrames par (m1, i1) (m2, i2) = unsafePerformIO $ do
-    let k = vocFreqFrameLength par
-    when (any ((/= k) . V.length) [m1, i1, m2, i2]) $ error "addFrames: frame length mismatch"
+addFrames :: STFTFrame -> STFTFrame -> STFTFrame
+addFrames (m1, i1) (m2, i2) = unsafePerformIO $ do
+    let k = minimum (map V.length [m1, i1, m2, i2])   -- zipWith, as in the reference
     mo <- MV.new k
     io <- MV.new k
-    withForeignPtr (vocCtx par) $ \ctx ->
-        V.unsafeWith m1 $ \pm1 -> V.unsafeWith i1 $ \pi1 -> V.unsafeWith m2 $ \pm2 -> V.unsafeWith i2 $ \pi2 ->
-            MV.unsafeWith mo $ \pmo -> MV.unsafeWith io $ \pio ->
-                check "addFrames" $ c_voc_add_frames ctx pm1 pi1 pm2 pi2 pmo pio 1
+    V.unsafeWith m1 $ \pm1 -> V.unsafeWith i1 $ \pi1 -> V.unsafeWith m2 $ \pm2 -> V.unsafeWith i2 $ \pi2 ->
+        MV.unsafeWith mo $ \pmo -> MV.unsafeWith io $ \pio ->
+            check "addFrames" $ c_voc_add_frames_n pm1 pi1 pm2 pi2 pmo pio (fromIntegral k)
     (,) <$> V.unsafeFreeze mo <*> V.unsafeFreeze io

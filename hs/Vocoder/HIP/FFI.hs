@@ -44,6 +44,20 @@ foreign import ccall safe "voc_synthesis_step" c_voc_synthesis_step
 foreign import ccall safe "voc_add_frames" c_voc_add_frames
     :: Ptr VocCtx -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Int64 -> IO Int32
 
+-- The reference's argument lists (no VocoderParams): hop, frame length, K, ... / hop, K, ...
+foreign import ccall safe "voc_analysis_step_hn" c_voc_analysis_step_hn
+    :: Int32 -> Int32 -> Int64 -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Int64 -> IO Int32
+foreign import ccall safe "voc_synthesis_step_h" c_voc_synthesis_step_h
+    :: Int32 -> Int64 -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Int64 -> IO Int32
+-- | spec (count complex), mag, ph, count
+foreign import ccall safe "voc_frame_from_complex" c_voc_frame_from_complex
+    :: Ptr Double -> Ptr Double -> Ptr Double -> Int64 -> IO Int32
+-- | mag, ph, spec (count complex), count
+foreign import ccall safe "voc_frame_to_complex" c_voc_frame_to_complex
+    :: Ptr Double -> Ptr Double -> Ptr Double -> Int64 -> IO Int32
+foreign import ccall safe "voc_add_frames_n" c_voc_add_frames_n
+    :: Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Int64 -> IO Int32
+
 -- | phase_io[C*K], frames[C*F*W], mag[C*F*K], ph_inc[C*F*K], channels, frames
 foreign import ccall safe "voc_analysis_stage" c_voc_analysis_stage
     :: Ptr VocCtx -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Int64 -> Int64 -> IO Int32
@@ -145,3 +159,16 @@ foreign import ccall safe "voc_roundtrip_dev" c_voc_roundtrip_dev
     -> Ptr Double -> Int64 -> Ptr () -> Int64 -> Ptr () -> IO Int32
 foreign import ccall unsafe "voc_roundtrip_workspace_bytes" c_voc_roundtrip_workspace_bytes
     :: Ptr VocCtx -> Int64 -> Int64 -> IO Int64
+-- | as voc_roundtrip_dev without workspace arguments: allocates nothing, refuses inputs whose per-channel
+--   scratch exceeds the library's static buffer
+foreign import ccall safe "voc_roundtrip_static_dev" c_voc_roundtrip_static_dev
+    :: Ptr VocCtx -> Ptr Double -> Int64 -> Int64 -> Int64 -> Int64 -> Ptr Double -> Int64 -> Ptr Double -> Ptr Double
+    -> Ptr Double -> Int64 -> Ptr () -> IO Int32
+-- | mag, ph_inc, ldk, nframes, channels, first_frame, first_channel, stream: the chain on a piece of a
+--   longer STFT (position-dependent filters number frames and channels from the given offsets)
+foreign import ccall safe "voc_filter_apply_at_dev" c_voc_filter_apply_at_dev
+    :: Ptr VocFilter -> Ptr Double -> Ptr Double -> Int64 -> Int64 -> Int64 -> Int64 -> Int64 -> Ptr () -> IO Int32
+-- | op (0 multiply, 1 divide, 2 add), mag1, inc1, mag2, inc2, mag_out, inc_out, count, stream
+foreign import ccall safe "voc_binary_frames_dev" c_voc_binary_frames_dev
+    :: Ptr VocCtx -> Int32 -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Int64
+    -> Ptr () -> IO Int32

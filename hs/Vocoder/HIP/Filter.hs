@@ -106,7 +106,7 @@ applyFilter par step (FilterDesc stages) frs = unsafePerformIO $ do
 --   frames, their outputs are added frame by frame with 'addFrames'.
 applyAddFilters :: Traversable t => VocoderParams -> FreqStep -> FilterDesc -> FilterDesc -> t STFTFrame -> t STFTFrame
 applyAddFilters par step f1 f2 frs = snd (mapAccumL pick (toList (applyFilter par step f2 frs)) (applyFilter par step f1 frs))
-    where pick (b : bs) a = (bs, addFrames par a b)
+    where pick (b : bs) a = (bs, addFrames a b)
           pick [] _ = error "applyAddFilters: containers of different shape"
 
 type FreqStep = Double

@@ -116,6 +116,25 @@ int32_t voc_add_frames(voc_ctx *ctx, const double *mag1, const double *inc1, con
 int32_t voc_add_frames_dev(voc_ctx *ctx, const double *mag1, const double *inc1, const double *mag2, const double *inc2,
                            double *mag_out, double *inc_out, int64_t count, void *stream);
 
+/* The same functions with the reference's own argument lists: analysisStep and synthesisStep take the
+ * hop size (and frame length) as plain numbers, frameFromComplex / frameToComplex / addFrames take only
+ * their vectors, none of them a VocoderParams.  These forms need no context: they run on the calling
+ * thread's current HIP device, keep one staging buffer for the process, and serialise among themselves.
+ *   voc_analysis_step_hn    analysisStep h eN prev_ph vec          Vocoder.hs:158-163   (K = length vec)
+ *   voc_synthesis_step_h    synthesisStep hop ph (mag, ph_inc)     Vocoder.hs:186-190
+ *   voc_frame_from_complex  frameFromComplex                       Vocoder.hs:217-218   spec: count complex
+ *   voc_frame_to_complex    frameToComplex                         Vocoder.hs:213-214
+ *   voc_add_frames_n        addFrames                              Vocoder.hs:220-222
+ */
+int32_t voc_analysis_step_hn(int32_t hop, int32_t frame_length, int64_t k, const double *prev_ph, const double *spec,
+                             double *ph_out, double *mag, double *ph_inc, int64_t batch);
+int32_t voc_synthesis_step_h(int32_t hop, int64_t k, const double *ph, const double *mag, const double *ph_inc,
+                             double *ph_out, double *spec, int64_t batch);
+int32_t voc_frame_from_complex(const double *spec, double *mag, double *ph, int64_t count);
+int32_t voc_frame_to_complex(const double *mag, const double *ph, double *spec, int64_t count);
+int32_t voc_add_frames_n(const double *mag1, const double *inc1, const double *mag2, const double *inc2,
+                         double *mag_out, double *inc_out, int64_t count);
+
 /* Element-wise combination of two STFT streams, as the `--multiply`, `--divide` and `--add` commands of
  * vocoder-jack combine them (vocoder-dunai/example/VocoderJack.hs:107-110,127-135):
  *   VOC_BINARY_MULTIPLY  mkBinary (*) (+): mag1 * mag2, ph_inc1 + ph_inc2

@@ -204,6 +204,22 @@ def synthesis_stage(n: int, hop: int, window, phase, mag, ph_inc):
     return ph, frames
 
 
+def frame_from_complex(spec):
+    """frameFromComplex (Vocoder.hs:217-218) -> (mag, phase)."""
+    spec = np.ascontiguousarray(spec, dtype=np.complex128).ravel()
+    mag, ph = np.empty(spec.size), np.empty(spec.size)
+    lib().orc_frame_from_complex(C.c_int(spec.size), _d(spec.view(np.float64)), _d(mag), _d(ph))
+    return mag, ph
+
+
+def frame_to_complex(mag, ph):
+    """frameToComplex (Vocoder.hs:213-214)."""
+    mag, ph = _f64(mag).ravel(), _f64(ph).ravel()
+    spec = np.empty(2 * mag.size)
+    lib().orc_frame_to_complex(C.c_int(mag.size), _d(mag), _d(ph), _d(spec))
+    return spec.view(np.complex128)
+
+
 def add_frames(mag1, inc1, mag2, inc2):
     mag1, inc1, mag2, inc2 = map(_f64, (mag1, inc1, mag2, inc2))
     k = mag1.size

@@ -178,3 +178,36 @@ def oracle_filtered(orc, n, hop, window, x, step, chain, speed=None, chunk=None)
     else:
         sph = np.zeros(k)
     return dict(y=y, mag=mag, ph_inc=inc, syn_phase=sph, ana_phase=rt["ana_phase"])
+
+
+def check_context_free_functions(lib, orc, rng, k, hop, n, batch=3):
+    """The forms of analysisStep / synthesisStep / frameFromComplex / frameToComplex / addFrames that
+    take the reference's own arguments (Vocoder.hs:158-163,186-190,213-222) against the oracle."""
+    from vocoder_amd import vocoder as V
+    spec = rng.standard_normal((batch, k)) + 1j * rng.standard_normal((batch, k))
+    spec[0, 1] = 0.0
+    spec[0, 0] = -2.0 + 0.0j
+    prev = rng.uniform(-3, 3, (batch, k))
+    ph, (mag, inc) = V.analysis_step(hop, n, prev, spec, lib=lib)
+    for b in range(batch):
+        rp, rm, ri = orc.analysis_step(hop, n, prev[b], spec[b])
+        assert np.abs(mag[b] - rm).max() <= 4e-16 * rm.max()
+        assert circ_dist(ph[b], rp).max() <= TOL_PHASE and circ_dist(inc[b] * hop, ri * hop).max() <= TOL_PHASE
+    assert ph[0, 1] == 0.0 and ph[0, 0] == np.pi
+    nph, sp = V.synthesis_step(hop, prev, (mag, inc), lib=lib)
+    for b in range(batch):
+        rp, rs = orc.synthesis_step(hop, prev[b], mag[b], inc[b])
+        assert np.array_equal(nph[b], rp) and rel_l2(sp[b], rs) <= TOL_L2
+    m, p = V.frame_from_complex(spec, lib=lib)
+    assert np.array_equal(m, mag) and np.array_equal(p, ph)       # the same device function as analysisStep's
+    back = V.frame_to_complex((m, p), lib=lib)
+    assert rel_l2(back, spec) <= TOL_L2
+    for b in range(batch):
+        rm, rp = orc.frame_from_complex(spec[b])
+        assert np.abs(m[b] - rm).max() <= 4e-16 * rm.max() and circ_dist(p[b], rp).max() <= TOL_PHASE
+        assert rel_l2(back[b], orc.frame_to_complex(rm, rp)) <= TOL_L2
+    m2, i2 = V.add_frames((mag, inc), (mag[::-1], inc[::-1]), lib=lib)
+    for b in range(batch):
+        rm, ri = orc.add_frames(mag[b], inc[b], mag[batch - 1 - b], inc[batch - 1 - b])
+        assert rel_l2(m2[b], rm) <= TOL_L2
+        assert circ_dist(i2[b], ri)[rm > 1e-9 * rm.max()].max() <= TOL_PHASE

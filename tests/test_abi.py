@@ -20,7 +20,8 @@ def test_header_declares_the_expected_surface():
     for must in ("voc_ctx_create", "voc_ctx_destroy", "voc_r2c", "voc_c2r", "voc_do_fft", "voc_do_ifft",
                  "voc_analysis_step", "voc_synthesis_step", "voc_analysis_stage", "voc_synthesis_stage",
                  "voc_analysis_stage_dev", "voc_synthesis_stage_dev", "voc_roundtrip", "voc_roundtrip_dev",
-                 "voc_frames_of", "voc_sum_frames", "voc_strerror"):
+                 "voc_frames_of", "voc_sum_frames", "voc_strerror", "voc_analysis_step_hn", "voc_synthesis_step_h",
+                 "voc_frame_from_complex", "voc_frame_to_complex", "voc_add_frames_n"):
         assert must in syms
 
 

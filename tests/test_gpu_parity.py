@@ -115,6 +115,16 @@ def test_steps_framing_and_ola(gpu_lib, orc):
     par.close()
 
 
+def test_functions_with_the_reference_argument_lists(gpu_lib, orc):
+    """analysisStep h eN, synthesisStep hop, frameFromComplex, frameToComplex and addFrames take no
+    VocoderParams in the reference (Vocoder.hs:158,186,213,217,221): the forms that need no context."""
+    Hh.check_context_free_functions(gpu_lib, orc, np.random.default_rng(8), k=2049, hop=1024, n=4096)
+    Hh.check_context_free_functions(gpu_lib, orc, np.random.default_rng(9), k=401, hop=200, n=800)
+    # many small calls in a row reuse one staging buffer
+    for i in range(50):
+        Hh.check_context_free_functions(gpu_lib, orc, np.random.default_rng(100 + i), k=17 + i, hop=4, n=32 + 2 * i, batch=1)
+
+
 def test_integer_framing_fixture_through_the_library(gpu_lib):
     """Framing and overlap-add move / add values without rounding when they are small integers:
     the library must reproduce the reference's list-model vectors exactly."""

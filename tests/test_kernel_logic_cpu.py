@@ -66,6 +66,11 @@ def test_steps_and_framing(emu_lib, orc):
     par.close()
 
 
+def test_functions_with_the_reference_argument_lists(emu_lib, orc):
+    Hh.check_context_free_functions(emu_lib, orc, np.random.default_rng(8), k=37, hop=12, n=72)
+    Hh.check_context_free_functions(emu_lib, orc, np.random.default_rng(9), k=33, hop=16, n=64)
+
+
 @pytest.mark.parametrize("slots,c", [(2, 5), (2, 4), (3, 4), (4, 5)])
 def test_uncut_leading_channels_equal_fully_tiled_result(emu_lib, orc, slots, c, monkeypatch):
     """With more channels than workgroup slots, whole rounds of channels run as one synthesis tile each

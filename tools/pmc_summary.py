@@ -1,6 +1,14 @@
-"""Summarises a rocprofv3 --pmc counter_collection.csv: per kernel name, mean of each counter."""
-import csv, sys, collections
+"""Summarises a rocprofv3 --pmc counter_collection.csv: per kernel name, mean of each counter over the
+dispatches.  With --json FILE the means are also merged into FILE ({kernel: {counter: mean}}), which
+tools/pmc_to_json.py turns into profiles/traffic.json and profiles/valu.json."""
+import collections
+import csv
+import json
+import os
+import sys
+
 path = sys.argv[1]
+jpath = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(path)):
     name = r['Kernel_Name']
@@ -8,7 +16,12 @@ for r in csv.DictReader(open(path)):
         continue
     short = name.split('(')[0].replace('void voc::', '')
     acc[short][r['Counter_Name']].append(float(r['Counter_Value']))
+merged = json.load(open(jpath)) if jpath and os.path.exists(jpath) else {}
 for k, d in acc.items():
     print(k)
     for cn, vals in d.items():
         print(f'   {cn:28s} mean {sum(vals)/len(vals):.4g}  (n={len(vals)})')
+        merged.setdefault(k, {})[cn] = sum(vals) / len(vals)
+        merged[k]["_dispatches_" + cn] = len(vals)
+if jpath:
+    json.dump(merged, open(jpath, "w"), indent=1, sort_keys=True)

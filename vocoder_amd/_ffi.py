@@ -35,6 +35,11 @@ SIGNATURES = {
     "voc_synthesis_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64]),
     "voc_add_frames": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64]),
     "voc_add_frames_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "voc_analysis_step_hn": (_i32, [_i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i64]),
+    "voc_synthesis_step_h": (_i32, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _i64]),
+    "voc_frame_from_complex": (_i32, [_vp, _vp, _vp, _i64]),
+    "voc_frame_to_complex": (_i32, [_vp, _vp, _vp, _i64]),
+    "voc_add_frames_n": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64]),
     "voc_analysis_stage": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64]),
     "voc_synthesis_stage": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64]),
     "voc_analysis_stage_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),

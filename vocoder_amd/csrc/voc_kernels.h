@@ -1138,6 +1138,24 @@ __global__ void add_frames_kernel(const double *mag1, const double *inc1, const 
     }
 }
 
+// frameFromComplex (Vocoder.hs:217-218) over `total` bins
+__global__ void frame_from_complex_kernel(const double *spec, double *mag, double *ph, long long total)
+{
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x)
+        hs_polar(spec[2 * g], spec[2 * g + 1], mag[g], ph[g]);
+}
+
+// frameToComplex (Vocoder.hs:213-214) over `total` bins
+__global__ void frame_to_complex_kernel(const double *mag, const double *ph, double *spec, long long total)
+{
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        double s, c;
+        fast_sincos(ph[g], &s, &c);
+        spec[2 * g] = mag[g] * c;
+        spec[2 * g + 1] = mag[g] * s;
+    }
+}
+
 // mkBinary op1 op2 (VocoderJack.hs:107-110): `--multiply` = (*) on the moduli, (+) on the increments;
 // `--divide` = (/) and (-)
 template <bool DIVIDE>

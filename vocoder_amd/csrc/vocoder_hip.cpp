@@ -36,6 +36,26 @@ static __device__ __align__(256) unsigned char voc_static_scratch[kStaticScratch
 alignas(256) static unsigned char voc_static_scratch[kStaticScratchBytes];
 #endif
 
+// Grow-only staging of the host-pointer entry points: one device buffer that holds the device images of
+// a call's host arrays, and one pinned host buffer through which small arrays travel (a copy from
+// pinned memory is a plain DMA; from pageable memory the runtime stages it and blocks).  Held by the
+// context (and one more for the entry points that take no context), so that a caller who crosses the
+// boundary once per frame -- Vocoder.Conduit.analysis / synthesis do (Conduit.hs:39,43) -- pays no
+// allocation per call.
+struct Staging {
+    char *dev = nullptr;
+    size_t dev_bytes = 0;
+    char *pin = nullptr;
+    size_t pin_bytes = 0;
+    void release()
+    {
+        if (dev) (void)hipFree(dev);
+        if (pin) (void)hipHostFree(pin);
+        dev = pin = nullptr;
+        dev_bytes = pin_bytes = 0;
+    }
+};
+
 struct voc_ctx {
     int N = 0, W = 0, H = 0, K = 0, M = 0, log2m = 0, device = 0;
     std::vector<double> window;
@@ -55,6 +75,7 @@ struct voc_ctx {
     voc::ParamsT<float> params_f{};
     void *ws = nullptr;
     size_t ws_bytes = 0;
+    Staging staging;  // host-pointer entry points
     // The library-owned workspace is shared by every call on the context, and _dev calls return
     // after enqueueing: ws_event marks the end of the last enqueued use, and a call on another HIP
     // stream waits for it before it touches the workspace.
@@ -108,13 +129,168 @@ int32_t guarded(voc_ctx *ctx, Body body)
     }
 }
 
-struct DevBuf {  // device allocation owned for the duration of one host-pointer call
-    void *p = nullptr;
-    explicit DevBuf(size_t bytes) { HIPCHK(hipMalloc(&p, bytes ? bytes : 8)); }
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    DevBuf(const DevBuf &) = delete;
-    DevBuf &operator=(const DevBuf &) = delete;
-    double *d() const { return static_cast<double *>(p); }
+// The device images of the host arrays of one host-pointer call, carved out of a Staging.  Usage: add()
+// every array (inputs first, then arrays that go both ways, outputs last), commit() once (grows the
+// staging if needed), upload() the inputs, uploads_done(), launch, download() the outputs, finish() (one
+// stream synchronisation, then the pinned images are copied to the caller).
+//
+// Arrays up to kPinPerArray travel through the pinned buffer, whose layout the front of the device
+// buffer mirrors: neighbouring arrays that move in the same direction go as ONE copy, so a one-frame
+// stage call costs one copy in, its kernels, one copy out and one synchronisation.  Larger arrays are
+// copied directly between the caller's memory and the device.
+class HostCall {
+public:
+    HostCall(Staging &s, hipStream_t st) : s_(s), st_(st) {}
+    HostCall(const HostCall &) = delete;
+    HostCall &operator=(const HostCall &) = delete;
+    int add(size_t bytes)
+    {
+        Buf b{};
+        b.bytes = bytes;
+        const size_t padded = (bytes + 255) / 256 * 256;
+        b.pinned = bytes <= kPinPerArray && pin_need_ + padded <= kPinTotal;
+        if (b.pinned) {
+            b.off = pin_need_;
+            pin_need_ += padded;
+        } else {
+            b.off = direct_need_;
+            direct_need_ += padded + 256;
+        }
+        bufs_.push_back(b);
+        return (int)bufs_.size() - 1;
+    }
+    void commit()
+    {
+        const size_t dev_need = pin_need_ + direct_need_ + 256;
+        if (dev_need > s_.dev_bytes) {
+            HIPCHK(hipDeviceSynchronize());
+            if (s_.dev) (void)hipFree(s_.dev);
+            s_.dev = nullptr;
+            s_.dev_bytes = 0;
+            HIPCHK(hipMalloc((void **)&s_.dev, dev_need));
+            s_.dev_bytes = dev_need;
+        }
+        if (pin_need_ > s_.pin_bytes) {
+            HIPCHK(hipDeviceSynchronize());
+            if (s_.pin) (void)hipHostFree(s_.pin);
+            s_.pin = nullptr;
+            s_.pin_bytes = 0;
+            HIPCHK(hipHostMalloc((void **)&s_.pin, pin_need_, 0));
+            s_.pin_bytes = pin_need_;
+        }
+        for (Buf &b : bufs_)
+            if (!b.pinned) b.off += pin_need_;  // the directly copied arrays follow the mirrored part
+    }
+    template <class T = double> T *dev(int i) const { return reinterpret_cast<T *>(s_.dev + bufs_[(size_t)i].off); }
+    void upload(int i, const void *host)
+    {
+        Buf &b = bufs_[(size_t)i];
+        if (b.bytes == 0) return;
+        if (b.pinned) {
+            std::memcpy(s_.pin + b.off, host, b.bytes);
+            b.moving = true;
+            pending_uploads_ = true;
+        } else {
+            HIPCHK(hipMemcpyAsync(s_.dev + b.off, host, b.bytes, hipMemcpyHostToDevice, st_));
+        }
+    }
+    // rows of `width` bytes, `host_pitch` bytes apart in the caller's array, packed on the device
+    void upload_rows(int i, const void *host, size_t host_pitch, size_t width, size_t rows)
+    {
+        if (width == 0 || rows == 0) return;
+        if (bufs_[(size_t)i].pinned) {
+            for (size_t r = 0; r < rows; ++r)
+                std::memcpy(s_.pin + bufs_[(size_t)i].off + r * width, (const char *)host + r * host_pitch, width);
+            bufs_[(size_t)i].moving = true;
+            pending_uploads_ = true;
+        } else {
+            HIPCHK(hipMemcpy2DAsync(s_.dev + bufs_[(size_t)i].off, width, host, host_pitch, width, rows, hipMemcpyHostToDevice, st_));
+        }
+    }
+    void uploads_done()  // before the first launch
+    {
+        move_runs(true);
+        pending_uploads_ = false;
+    }
+    void download(int i, void *host)
+    {
+        if (pending_uploads_) throw StatusFail{VOC_ERR_INVALID};
+        Buf &b = bufs_[(size_t)i];
+        if (b.bytes == 0) return;
+        if (b.pinned) {
+            b.moving = true;
+            b.deliver_to = host;
+            b.deliver_pitch = b.deliver_width = b.bytes;
+        } else {
+            HIPCHK(hipMemcpyAsync(host, s_.dev + b.off, b.bytes, hipMemcpyDeviceToHost, st_));
+        }
+    }
+    void download_rows(int i, void *host, size_t host_pitch, size_t width, size_t rows)
+    {
+        if (pending_uploads_) throw StatusFail{VOC_ERR_INVALID};
+        if (width == 0 || rows == 0) return;
+        Buf &b = bufs_[(size_t)i];
+        if (b.pinned) {
+            b.moving = true;
+            b.deliver_to = host;
+            b.deliver_pitch = host_pitch;
+            b.deliver_width = width;
+        } else {
+            HIPCHK(hipMemcpy2DAsync(host, host_pitch, s_.dev + b.off, width, width, rows, hipMemcpyDeviceToHost, st_));
+        }
+    }
+    void finish()
+    {
+        if (pending_uploads_) throw StatusFail{VOC_ERR_INVALID};
+        move_runs(false);
+        HIPCHK(hipStreamSynchronize(st_));
+        for (Buf &b : bufs_)
+            if (b.deliver_to) {
+                const char *src = s_.pin + b.off;
+                for (size_t done = 0, r = 0; done + b.deliver_width <= b.bytes; done += b.deliver_width, ++r)
+                    std::memcpy((char *)b.deliver_to + r * b.deliver_pitch, src + done, b.deliver_width);
+                b.deliver_to = nullptr;
+            }
+    }
+
+private:
+    static constexpr size_t kPinPerArray = (size_t)4 << 20, kPinTotal = (size_t)32 << 20;
+    struct Buf {
+        size_t bytes, off;  // off: into the device buffer, and into the pinned one for pinned arrays
+        bool pinned, moving;
+        void *deliver_to;
+        size_t deliver_pitch, deliver_width;
+    };
+    // one copy per run of neighbouring pinned arrays marked `moving`
+    void move_runs(bool to_device)
+    {
+        size_t lo = 0, hi = 0;
+        auto flush = [&]() {
+            if (hi > lo) {
+                if (to_device)
+                    HIPCHK(hipMemcpyAsync(s_.dev + lo, s_.pin + lo, hi - lo, hipMemcpyHostToDevice, st_));
+                else
+                    HIPCHK(hipMemcpyAsync(s_.pin + lo, s_.dev + lo, hi - lo, hipMemcpyDeviceToHost, st_));
+            }
+            lo = hi = 0;
+        };
+        for (Buf &b : bufs_) {
+            if (!b.pinned) continue;
+            if (b.moving) {
+                if (hi == lo) lo = b.off;
+                hi = b.off + b.bytes;
+                b.moving = false;
+            } else if (b.bytes > 0) {
+                flush();
+            }
+        }
+        flush();
+    }
+    Staging &s_;
+    hipStream_t st_;
+    std::vector<Buf> bufs_;
+    size_t pin_need_ = 0, direct_need_ = 0;
+    bool pending_uploads_ = false;
 };
 
 enum { KIND_ANALYSIS = 0, KIND_CARRY = 1, KIND_SYNTHESIS = 2, KIND_OTHER = 3, KIND_COUNT = 4 };
@@ -998,6 +1174,7 @@ VOC_EXPORT int32_t voc_ctx_destroy(voc_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->ws) { (void)hipDeviceSynchronize(); (void)hipFree(c->ws); }
     if (c->ws_event) (void)hipEventDestroy(c->ws_event);
+    c->staging.release();
     if (c->d_window) (void)hipFree(c->d_window);
     if (c->d_twP) (void)hipFree(c->d_twP);
     if (c->d_twS) (void)hipFree(c->d_twS);
@@ -1041,20 +1218,24 @@ int32_t spec_forward(voc_ctx *c, const double *in, double *out, int64_t B)
     return guarded(c, [&]() -> int32_t {
         Locked lk(c);
         const size_t in_len = RAW ? (size_t)c->N : (size_t)c->W;
-        DevBuf din((size_t)B * in_len * sizeof(double)), dout((size_t)B * c->K * 2 * sizeof(double));
-        HIPCHK(hipMemcpy(din.p, in, (size_t)B * in_len * sizeof(double), hipMemcpyHostToDevice));
+        HostCall h(c->staging, nullptr);
+        const int din = h.add((size_t)B * in_len * sizeof(double)), dout = h.add((size_t)B * c->K * 2 * sizeof(double));
+        h.commit();
+        h.upload(din, in);
+        h.uploads_done();
         voc::AnaArgs a{};
-        a.x = din.d();
+        a.x = h.dev(din);
         a.chan_stride = 0;
         a.frame_stride = (long long)in_len;
-        a.spec = dout.d();
+        a.spec = h.dev(dout);
         a.F = B;
         a.rpc = B;
         a.tile_len = 4;
         a.tiles = (int)((B + 3) / 4);
         a.vol = 1.0;
         launch_analysis<RAW, true>(c, a, 1, nullptr);
-        HIPCHK(hipMemcpy(out, dout.p, (size_t)B * c->K * 2 * sizeof(double), hipMemcpyDeviceToHost));
+        h.download(dout, out);
+        h.finish();
         return VOC_OK;
     });
 }
@@ -1067,16 +1248,20 @@ int32_t spec_backward(voc_ctx *c, const double *in, double *out, int64_t B)
     return guarded(c, [&]() -> int32_t {
         Locked lk(c);
         const size_t out_len = OUT_MODE == voc::SYN_OUT_RAW ? (size_t)c->N : (size_t)c->W;
-        DevBuf din((size_t)B * c->K * 2 * sizeof(double)), dout((size_t)B * out_len * sizeof(double));
-        HIPCHK(hipMemcpy(din.p, in, (size_t)B * c->K * 2 * sizeof(double), hipMemcpyHostToDevice));
+        HostCall h(c->staging, nullptr);
+        const int din = h.add((size_t)B * c->K * 2 * sizeof(double)), dout = h.add((size_t)B * out_len * sizeof(double));
+        h.commit();
+        h.upload(din, in);
+        h.uploads_done();
         voc::SynArgs a{};
-        a.spec = din.d();
-        a.out = dout.d();
+        a.spec = h.dev(din);
+        a.out = h.dev(dout);
         a.F = B;
         a.tile_len = 4;
         a.tiles = (int)((B + 3) / 4);
         launch_synthesis<voc::SYN_IN_SPEC, OUT_MODE>(c, a, 1, nullptr);
-        HIPCHK(hipMemcpy(out, dout.p, (size_t)B * out_len * sizeof(double), hipMemcpyDeviceToHost));
+        h.download(dout, out);
+        h.finish();
         return VOC_OK;
     });
 }
@@ -1097,15 +1282,19 @@ VOC_EXPORT int32_t voc_analysis_step(voc_ctx *c, const double *prev_ph, const do
     return guarded(c, [&]() -> int32_t {
         Locked lk(c);
         const size_t n = (size_t)B * c->K, nb = n * sizeof(double);
-        DevBuf dprev(nb), dspec(2 * nb), dph(nb), dmag(nb), dinc(nb);
-        HIPCHK(hipMemcpy(dprev.p, prev_ph, nb, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(dspec.p, spec, 2 * nb, hipMemcpyHostToDevice));
+        HostCall h(c->staging, nullptr);
+        const int dprev = h.add(nb), dspec = h.add(2 * nb), dph = h.add(nb), dmag = h.add(nb), dinc = h.add(nb);
+        h.commit();
+        h.upload(dprev, prev_ph);
+        h.upload(dspec, spec);
+        h.uploads_done();
         hipLaunchKernelGGL(voc::analysis_step_kernel, dim3(ew_grid((long long)n)), dim3(256), 0, nullptr, c->params,
-                           dprev.d(), dspec.d(), dph.d(), dmag.d(), dinc.d(), (long long)n);
+                           h.dev(dprev), h.dev(dspec), h.dev(dph), h.dev(dmag), h.dev(dinc), (long long)n);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpy(ph_out, dph.p, nb, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(mag, dmag.p, nb, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(ph_inc, dinc.p, nb, hipMemcpyDeviceToHost));
+        h.download(dph, ph_out);
+        h.download(dmag, mag);
+        h.download(dinc, ph_inc);
+        h.finish();
         return VOC_OK;
     });
 }
@@ -1118,15 +1307,19 @@ VOC_EXPORT int32_t voc_synthesis_step(voc_ctx *c, const double *ph, const double
     return guarded(c, [&]() -> int32_t {
         Locked lk(c);
         const size_t n = (size_t)B * c->K, nb = n * sizeof(double);
-        DevBuf dph(nb), dmag(nb), dinc(nb), dout(nb), dspec(2 * nb);
-        HIPCHK(hipMemcpy(dph.p, ph, nb, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(dmag.p, mag, nb, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(dinc.p, ph_inc, nb, hipMemcpyHostToDevice));
+        HostCall h(c->staging, nullptr);
+        const int dph = h.add(nb), dmag = h.add(nb), dinc = h.add(nb), dout = h.add(nb), dspec = h.add(2 * nb);
+        h.commit();
+        h.upload(dph, ph);
+        h.upload(dmag, mag);
+        h.upload(dinc, ph_inc);
+        h.uploads_done();
         hipLaunchKernelGGL(voc::synthesis_step_kernel, dim3(ew_grid((long long)n)), dim3(256), 0, nullptr, c->params,
-                           dph.d(), dmag.d(), dinc.d(), dout.d(), dspec.d(), (long long)n);
+                           h.dev(dph), h.dev(dmag), h.dev(dinc), h.dev(dout), h.dev(dspec), (long long)n);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpy(ph_out, dout.p, nb, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(spec, dspec.p, 2 * nb, hipMemcpyDeviceToHost));
+        h.download(dout, ph_out);
+        h.download(dspec, spec);
+        h.finish();
         return VOC_OK;
     });
 }
@@ -1139,16 +1332,170 @@ VOC_EXPORT int32_t voc_add_frames(voc_ctx *c, const double *mag1, const double *
     return guarded(c, [&]() -> int32_t {
         Locked lk(c);
         const size_t n = (size_t)B * c->K, nb = n * sizeof(double);
-        DevBuf a(nb), b(nb), d(nb), e(nb), mo(nb), io(nb);
-        HIPCHK(hipMemcpy(a.p, mag1, nb, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(b.p, inc1, nb, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(d.p, mag2, nb, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(e.p, inc2, nb, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(voc::add_frames_kernel, dim3(ew_grid((long long)n)), dim3(256), 0, nullptr, a.d(), b.d(),
-                           d.d(), e.d(), mo.d(), io.d(), (long long)n);
+        HostCall h(c->staging, nullptr);
+        const int a = h.add(nb), b = h.add(nb), d = h.add(nb), e = h.add(nb), mo = h.add(nb), io = h.add(nb);
+        h.commit();
+        h.upload(a, mag1);
+        h.upload(b, inc1);
+        h.upload(d, mag2);
+        h.upload(e, inc2);
+        h.uploads_done();
+        hipLaunchKernelGGL(voc::add_frames_kernel, dim3(ew_grid((long long)n)), dim3(256), 0, nullptr, h.dev(a), h.dev(b),
+                           h.dev(d), h.dev(e), h.dev(mo), h.dev(io), (long long)n);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpy(mag_out, mo.p, nb, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(inc_out, io.p, nb, hipMemcpyDeviceToHost));
+        h.download(mo, mag_out);
+        h.download(io, inc_out);
+        h.finish();
+        return VOC_OK;
+    });
+}
+
+// ---- the reference's functions that take no VocoderParams ----------------------------------------------
+//
+// analysisStep, synthesisStep, frameFromComplex, frameToComplex and addFrames (Vocoder.hs:158,186,213,217,
+// 221) are functions of their vectors (and of hop / length where given) alone.  These forms take no
+// context: they run on the calling thread's current HIP device, share one staging buffer, and
+// serialise among themselves.
+
+namespace {
+std::mutex g_free_mu;
+Staging g_free_staging;  // lives until the process ends
+
+voc::Params step_params(int hop, int n, long long k)
+{
+    voc::Params p{};
+    p.N = n;
+    p.H = hop;
+    p.K = (int)k;
+    p.hop_pow2 = (hop & (hop - 1)) == 0;
+    p.hop_d = (double)hop;
+    p.inv_hop = 1.0 / (double)hop;
+    p.inv_n = 1.0 / (double)n;
+    p.omega1 = (p.hop_pow2 && (n & (n - 1)) == 0) ? (voc::kTwoPi * (double)hop) / (double)n : 0.0;
+    return p;
+}
+}  // namespace
+
+VOC_EXPORT int32_t voc_analysis_step_hn(int32_t hop, int32_t n, int64_t K, const double *prev_ph, const double *spec,
+                                        double *ph_out, double *mag, double *ph_inc, int64_t B)
+{
+    if (hop < 1 || n < 1 || K < 0 || K > INT32_MAX || B < 0) return VOC_ERR_INVALID;
+    if (B * K > 0 && (!prev_ph || !spec || !ph_out || !mag || !ph_inc)) return VOC_ERR_INVALID;
+    if (B * K == 0) return VOC_OK;
+    return guarded(nullptr, [&]() -> int32_t {
+        std::lock_guard<std::mutex> g(g_free_mu);
+        const size_t cnt = (size_t)B * (size_t)K, nb = cnt * sizeof(double);
+        HostCall h(g_free_staging, nullptr);
+        const int dprev = h.add(nb), dspec = h.add(2 * nb), dph = h.add(nb), dmag = h.add(nb), dinc = h.add(nb);
+        h.commit();
+        h.upload(dprev, prev_ph);
+        h.upload(dspec, spec);
+        h.uploads_done();
+        hipLaunchKernelGGL(voc::analysis_step_kernel, dim3(ew_grid((long long)cnt)), dim3(256), 0, nullptr,
+                           step_params(hop, n, K), h.dev(dprev), h.dev(dspec), h.dev(dph), h.dev(dmag), h.dev(dinc),
+                           (long long)cnt);
+        HIPCHK(hipGetLastError());
+        h.download(dph, ph_out);
+        h.download(dmag, mag);
+        h.download(dinc, ph_inc);
+        h.finish();
+        return VOC_OK;
+    });
+}
+
+VOC_EXPORT int32_t voc_synthesis_step_h(int32_t hop, int64_t K, const double *ph, const double *mag, const double *ph_inc,
+                                        double *ph_out, double *spec, int64_t B)
+{
+    if (hop < 1 || K < 0 || K > INT32_MAX || B < 0) return VOC_ERR_INVALID;
+    if (B * K > 0 && (!ph || !mag || !ph_inc || !ph_out || !spec)) return VOC_ERR_INVALID;
+    if (B * K == 0) return VOC_OK;
+    return guarded(nullptr, [&]() -> int32_t {
+        std::lock_guard<std::mutex> g(g_free_mu);
+        const size_t cnt = (size_t)B * (size_t)K, nb = cnt * sizeof(double);
+        HostCall h(g_free_staging, nullptr);
+        const int dph = h.add(nb), dmag = h.add(nb), dinc = h.add(nb), dout = h.add(nb), dspec = h.add(2 * nb);
+        h.commit();
+        h.upload(dph, ph);
+        h.upload(dmag, mag);
+        h.upload(dinc, ph_inc);
+        h.uploads_done();
+        hipLaunchKernelGGL(voc::synthesis_step_kernel, dim3(ew_grid((long long)cnt)), dim3(256), 0, nullptr,
+                           step_params(hop, 2, K), h.dev(dph), h.dev(dmag), h.dev(dinc), h.dev(dout), h.dev(dspec),
+                           (long long)cnt);
+        HIPCHK(hipGetLastError());
+        h.download(dout, ph_out);
+        h.download(dspec, spec);
+        h.finish();
+        return VOC_OK;
+    });
+}
+
+VOC_EXPORT int32_t voc_frame_from_complex(const double *spec, double *mag, double *ph, int64_t count)
+{
+    if (count < 0 || (count > 0 && (!spec || !mag || !ph))) return VOC_ERR_INVALID;
+    if (count == 0) return VOC_OK;
+    return guarded(nullptr, [&]() -> int32_t {
+        std::lock_guard<std::mutex> g(g_free_mu);
+        const size_t nb = (size_t)count * sizeof(double);
+        HostCall h(g_free_staging, nullptr);
+        const int dspec = h.add(2 * nb), dmag = h.add(nb), dph = h.add(nb);
+        h.commit();
+        h.upload(dspec, spec);
+        h.uploads_done();
+        hipLaunchKernelGGL(voc::frame_from_complex_kernel, dim3(ew_grid((long long)count)), dim3(256), 0, nullptr,
+                           h.dev(dspec), h.dev(dmag), h.dev(dph), (long long)count);
+        HIPCHK(hipGetLastError());
+        h.download(dmag, mag);
+        h.download(dph, ph);
+        h.finish();
+        return VOC_OK;
+    });
+}
+
+VOC_EXPORT int32_t voc_frame_to_complex(const double *mag, const double *ph, double *spec, int64_t count)
+{
+    if (count < 0 || (count > 0 && (!spec || !mag || !ph))) return VOC_ERR_INVALID;
+    if (count == 0) return VOC_OK;
+    return guarded(nullptr, [&]() -> int32_t {
+        std::lock_guard<std::mutex> g(g_free_mu);
+        const size_t nb = (size_t)count * sizeof(double);
+        HostCall h(g_free_staging, nullptr);
+        const int dmag = h.add(nb), dph = h.add(nb), dspec = h.add(2 * nb);
+        h.commit();
+        h.upload(dmag, mag);
+        h.upload(dph, ph);
+        h.uploads_done();
+        hipLaunchKernelGGL(voc::frame_to_complex_kernel, dim3(ew_grid((long long)count)), dim3(256), 0, nullptr,
+                           h.dev(dmag), h.dev(dph), h.dev(dspec), (long long)count);
+        HIPCHK(hipGetLastError());
+        h.download(dspec, spec);
+        h.finish();
+        return VOC_OK;
+    });
+}
+
+VOC_EXPORT int32_t voc_add_frames_n(const double *mag1, const double *inc1, const double *mag2, const double *inc2,
+                                    double *mag_out, double *inc_out, int64_t count)
+{
+    if (count < 0 || (count > 0 && (!mag1 || !inc1 || !mag2 || !inc2 || !mag_out || !inc_out))) return VOC_ERR_INVALID;
+    if (count == 0) return VOC_OK;
+    return guarded(nullptr, [&]() -> int32_t {
+        std::lock_guard<std::mutex> g(g_free_mu);
+        const size_t nb = (size_t)count * sizeof(double);
+        HostCall h(g_free_staging, nullptr);
+        const int a = h.add(nb), b = h.add(nb), d = h.add(nb), e = h.add(nb), mo = h.add(nb), io = h.add(nb);
+        h.commit();
+        h.upload(a, mag1);
+        h.upload(b, inc1);
+        h.upload(d, mag2);
+        h.upload(e, inc2);
+        h.uploads_done();
+        hipLaunchKernelGGL(voc::add_frames_kernel, dim3(ew_grid((long long)count)), dim3(256), 0, nullptr, h.dev(a),
+                           h.dev(b), h.dev(d), h.dev(e), h.dev(mo), h.dev(io), (long long)count);
+        HIPCHK(hipGetLastError());
+        h.download(mo, mag_out);
+        h.download(io, inc_out);
+        h.finish();
         return VOC_OK;
     });
 }
@@ -1223,13 +1570,17 @@ VOC_EXPORT int32_t voc_analysis_stage(voc_ctx *c, double *phase_io, const double
         Locked lk(c);
         const size_t nph = (size_t)C * c->K * sizeof(double), nfr = (size_t)C * F * c->W * sizeof(double),
                      nst = (size_t)C * F * c->K * sizeof(double);
-        DevBuf dph(nph), dfr(nfr), dmag(nst), dinc(nst);
-        HIPCHK(hipMemcpy(dph.p, phase_io, nph, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(dfr.p, frames, nfr, hipMemcpyHostToDevice));
-        analysis_stage_dev(c, dph.d(), dfr.d(), dmag.d(), dinc.d(), C, F, nullptr);
-        HIPCHK(hipMemcpy(phase_io, dph.p, nph, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(mag, dmag.p, nst, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(ph_inc, dinc.p, nst, hipMemcpyDeviceToHost));
+        HostCall h(c->staging, nullptr);
+        const int dfr = h.add(nfr), dph = h.add(nph), dmag = h.add(nst), dinc = h.add(nst);
+        h.commit();
+        h.upload(dfr, frames);
+        h.upload(dph, phase_io);
+        h.uploads_done();
+        analysis_stage_dev(c, h.dev(dph), h.dev(dfr), h.dev(dmag), h.dev(dinc), C, F, nullptr);
+        h.download(dph, phase_io);
+        h.download(dmag, mag);
+        h.download(dinc, ph_inc);
+        h.finish();
         return VOC_OK;
     });
 }
@@ -1244,13 +1595,17 @@ VOC_EXPORT int32_t voc_synthesis_stage(voc_ctx *c, double *phase_io, const doubl
         Locked lk(c);
         const size_t nph = (size_t)C * c->K * sizeof(double), nfr = (size_t)C * F * c->W * sizeof(double),
                      nst = (size_t)C * F * c->K * sizeof(double);
-        DevBuf dph(nph), dfr(nfr), dmag(nst), dinc(nst);
-        HIPCHK(hipMemcpy(dph.p, phase_io, nph, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(dmag.p, mag, nst, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(dinc.p, ph_inc, nst, hipMemcpyHostToDevice));
-        synthesis_stage_dev(c, dph.d(), dmag.d(), dinc.d(), dfr.d(), C, F, nullptr);
-        HIPCHK(hipMemcpy(phase_io, dph.p, nph, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(frames, dfr.p, nfr, hipMemcpyDeviceToHost));
+        HostCall h(c->staging, nullptr);
+        const int dmag = h.add(nst), dinc = h.add(nst), dph = h.add(nph), dfr = h.add(nfr);
+        h.commit();
+        h.upload(dph, phase_io);
+        h.upload(dmag, mag);
+        h.upload(dinc, ph_inc);
+        h.uploads_done();
+        synthesis_stage_dev(c, h.dev(dph), h.dev(dmag), h.dev(dinc), h.dev(dfr), C, F, nullptr);
+        h.download(dph, phase_io);
+        h.download(dfr, frames);
+        h.finish();
         return VOC_OK;
     });
 }
@@ -1266,13 +1621,17 @@ VOC_EXPORT int32_t voc_frames_of(voc_ctx *c, const double *x, int64_t x_stride, 
     return guarded(c, [&]() -> int32_t {
         Locked lk(c);
         const size_t nx = (size_t)C * x_stride * sizeof(double), nfr = (size_t)C * F * c->W * sizeof(double);
-        DevBuf dx(nx), dfr(nfr);
-        HIPCHK(hipMemcpy(dx.p, x, nx, hipMemcpyHostToDevice));
+        HostCall h(c->staging, nullptr);
+        const int dx = h.add(nx), dfr = h.add(nfr);
+        h.commit();
+        h.upload(dx, x);
+        h.uploads_done();
         const long long total = C * F * c->W;
-        hipLaunchKernelGGL(voc::frames_of_kernel, dim3(ew_grid(total)), dim3(256), 0, nullptr, dx.d(),
-                           (long long)x_stride, dfr.d(), F, c->W, c->H, total);
+        hipLaunchKernelGGL(voc::frames_of_kernel, dim3(ew_grid(total)), dim3(256), 0, nullptr, h.dev(dx),
+                           (long long)x_stride, h.dev(dfr), F, c->W, c->H, total);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpy(frames, dfr.p, nfr, hipMemcpyDeviceToHost));
+        h.download(dfr, frames);
+        h.finish();
         return VOC_OK;
     });
 }
@@ -1287,14 +1646,18 @@ VOC_EXPORT int32_t voc_sum_frames(voc_ctx *c, const double *frames, int64_t F, i
     return guarded(c, [&]() -> int32_t {
         Locked lk(c);
         const size_t nfr = (size_t)C * F * c->W * sizeof(double), ny = (size_t)C * y_stride * sizeof(double);
-        DevBuf dfr(nfr), dy(ny);
-        HIPCHK(hipMemcpy(dfr.p, frames, nfr, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(dy.p, y, ny, hipMemcpyHostToDevice));  // keeps the caller's bytes between rows
+        HostCall h(c->staging, nullptr);
+        const int dfr = h.add(nfr), dy = h.add(ny);
+        h.commit();
+        h.upload(dfr, frames);
+        h.upload(dy, y);  // keeps the caller's bytes between rows
+        h.uploads_done();
         const long long total = C * out_len;
-        hipLaunchKernelGGL(voc::sum_frames_kernel<double>, dim3(ew_grid(total)), dim3(256), 0, nullptr, dfr.d(), (long long)F,
-                           c->W, c->H, dy.d(), (long long)y_stride, out_len, total);
+        hipLaunchKernelGGL(voc::sum_frames_kernel<double>, dim3(ew_grid(total)), dim3(256), 0, nullptr, h.dev(dfr), (long long)F,
+                           c->W, c->H, h.dev(dy), (long long)y_stride, out_len, total);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpy(y, dy.p, ny, hipMemcpyDeviceToHost));
+        h.download(dy, y);
+        h.finish();
         return VOC_OK;
     });
 }
@@ -1440,22 +1803,20 @@ VOC_EXPORT int32_t voc_roundtrip(voc_ctx *c, const double *x, int64_t x_stride, 
         Locked lk(c);
         const size_t nx = (size_t)C * len * sizeof(double), ny = (size_t)C * out_len * sizeof(double),
                      nph = (size_t)C * c->K * sizeof(double), nl = (size_t)C * keep * sizeof(double);
-        DevBuf dx(nx), dy(ny), da(nph), ds(nph), dl(nl);
-        HIPCHK(hipMemcpy2DAsync(dx.p, (size_t)len * sizeof(double), x, (size_t)x_stride * sizeof(double),
-                                (size_t)len * sizeof(double), (size_t)C, hipMemcpyHostToDevice, nullptr));
-        HIPCHK(hipMemcpy(da.p, ana_phase_io, nph, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(ds.p, syn_phase_io, nph, hipMemcpyHostToDevice));
-        roundtrip_dev(c, dx.d(), len, len, C, chunk, dy.d(), out_len, da.d(), ds.d(), leftover ? dl.d() : nullptr, keep,
-                      nullptr, 0, nullptr);
-        HIPCHK(hipStreamSynchronize(nullptr));
-        if (out_len > 0)
-            HIPCHK(hipMemcpy2DAsync(y, (size_t)y_stride * sizeof(double), dy.p, (size_t)out_len * sizeof(double),
-                                    (size_t)out_len * sizeof(double), (size_t)C, hipMemcpyDeviceToHost, nullptr));
-        if (leftover && keep > 0)
-            HIPCHK(hipMemcpy2DAsync(leftover, (size_t)leftover_stride * sizeof(double), dl.p, (size_t)keep * sizeof(double),
-                                    (size_t)keep * sizeof(double), (size_t)C, hipMemcpyDeviceToHost, nullptr));
-        HIPCHK(hipMemcpy(ana_phase_io, da.p, nph, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(syn_phase_io, ds.p, nph, hipMemcpyDeviceToHost));
+        HostCall h(c->staging, nullptr);
+        const int dx = h.add(nx), da = h.add(nph), ds = h.add(nph), dy = h.add(ny), dl = h.add(nl);
+        h.commit();
+        h.upload_rows(dx, x, (size_t)x_stride * sizeof(double), (size_t)len * sizeof(double), (size_t)C);
+        h.upload(da, ana_phase_io);
+        h.upload(ds, syn_phase_io);
+        h.uploads_done();
+        roundtrip_dev(c, h.dev(dx), len, len, C, chunk, h.dev(dy), out_len, h.dev(da), h.dev(ds),
+                      leftover ? h.dev(dl) : nullptr, keep, nullptr, 0, nullptr);
+        h.download_rows(dy, y, (size_t)y_stride * sizeof(double), (size_t)out_len * sizeof(double), (size_t)C);
+        if (leftover) h.download_rows(dl, leftover, (size_t)leftover_stride * sizeof(double), (size_t)keep * sizeof(double), (size_t)C);
+        h.download(da, ana_phase_io);
+        h.download(ds, syn_phase_io);
+        h.finish();
         return VOC_OK;
     });
 }
@@ -1497,23 +1858,20 @@ VOC_EXPORT int32_t voc_roundtrip_f32(voc_ctx *c, const float *x, int64_t x_strid
         const size_t e = sizeof(float);
         const size_t nx = (size_t)C * len * e, ny = (size_t)C * out_len * e, nph = (size_t)C * c->K * e,
                      nl = (size_t)C * keep * e;
-        DevBuf dx(nx), dy(ny), da(nph), ds(nph), dl(nl);
-        HIPCHK(hipMemcpy2DAsync(dx.p, (size_t)len * e, x, (size_t)x_stride * e, (size_t)len * e, (size_t)C,
-                                hipMemcpyHostToDevice, nullptr));
-        HIPCHK(hipMemcpy(da.p, ana_phase_io, nph, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(ds.p, syn_phase_io, nph, hipMemcpyHostToDevice));
-        roundtrip_dev<float>(c, static_cast<float *>(dx.p), len, len, C, chunk, static_cast<float *>(dy.p), out_len,
-                             static_cast<float *>(da.p), static_cast<float *>(ds.p),
-                             leftover ? static_cast<float *>(dl.p) : nullptr, keep, nullptr, 0, nullptr);
-        HIPCHK(hipStreamSynchronize(nullptr));
-        if (out_len > 0)
-            HIPCHK(hipMemcpy2DAsync(y, (size_t)y_stride * e, dy.p, (size_t)out_len * e, (size_t)out_len * e, (size_t)C,
-                                    hipMemcpyDeviceToHost, nullptr));
-        if (leftover && keep > 0)
-            HIPCHK(hipMemcpy2DAsync(leftover, (size_t)leftover_stride * e, dl.p, (size_t)keep * e, (size_t)keep * e,
-                                    (size_t)C, hipMemcpyDeviceToHost, nullptr));
-        HIPCHK(hipMemcpy(ana_phase_io, da.p, nph, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(syn_phase_io, ds.p, nph, hipMemcpyDeviceToHost));
+        HostCall h(c->staging, nullptr);
+        const int dx = h.add(nx), da = h.add(nph), ds = h.add(nph), dy = h.add(ny), dl = h.add(nl);
+        h.commit();
+        h.upload_rows(dx, x, (size_t)x_stride * e, (size_t)len * e, (size_t)C);
+        h.upload(da, ana_phase_io);
+        h.upload(ds, syn_phase_io);
+        h.uploads_done();
+        roundtrip_dev<float>(c, h.dev<float>(dx), len, len, C, chunk, h.dev<float>(dy), out_len, h.dev<float>(da),
+                             h.dev<float>(ds), leftover ? h.dev<float>(dl) : nullptr, keep, nullptr, 0, nullptr);
+        h.download_rows(dy, y, (size_t)y_stride * e, (size_t)out_len * e, (size_t)C);
+        if (leftover) h.download_rows(dl, leftover, (size_t)leftover_stride * e, (size_t)keep * e, (size_t)C);
+        h.download(da, ana_phase_io);
+        h.download(ds, syn_phase_io);
+        h.finish();
         return VOC_OK;
     });
 }

@@ -19,7 +19,7 @@ __all__ = [
     "VocoderParams", "vocoder_params", "voc_frame_length", "voc_input_frame_length", "voc_freq_frame_length",
     "voc_hop_size", "voc_window", "do_fft", "do_ifft", "analysis_block", "analysis_step", "analysis_stage",
     "synthesis_block", "synthesis_step", "synthesis_stage", "zero_phase", "volume_coeff", "add_frames",
-    "fft_execute_r2c", "fft_execute_c2r", "VocoderError",
+    "fft_execute_r2c", "fft_execute_c2r", "frame_from_complex", "frame_to_complex", "VocoderError",
 ]
 
 
@@ -155,42 +155,94 @@ def do_ifft(par, spec) -> np.ndarray:
     return out.reshape(lead + (par.W,))
 
 
-def analysis_step(par, prev_ph, spec):
-    """analysisStep h eN prev_ph vec -> (ph, (mag, ph_inc)) (Vocoder.hs:158-163); h and eN come
-    from `par`."""
-    spec, lead = _batched(spec, par.K, np.complex128)
-    prev_ph, _ = _batched(prev_ph, par.K)
-    b = spec.shape[0]
-    ph, mag, inc = np.empty((b, par.K)), np.empty((b, par.K)), np.empty((b, par.K))
-    par._call("voc_analysis_step", _p(prev_ph), _p(spec), _p(ph), _p(mag), _p(inc), b)
-    sh = lead + (par.K,)
+def _free_call(lib, name, *args):
+    lib = lib or default_library()
+    lib.check(getattr(lib.dll, name)(*args))
+
+
+def analysis_step(par_or_hop, *args, lib: Library | None = None):
+    """analysisStep h eN prev_ph vec -> (ph, (mag, ph_inc)) (Vocoder.hs:158-163).
+
+    Either the reference's own argument list, `analysis_step(h, eN, prev_ph, vec)`, or
+    `analysis_step(par, prev_ph, vec)` with h and eN taken from `par`."""
+    if isinstance(par_or_hop, VocoderParams):
+        par = par_or_hop
+        prev_ph, spec = args
+        spec, lead = _batched(spec, par.K, np.complex128)
+        prev_ph, _ = _batched(prev_ph, par.K)
+        b, k = spec.shape[0], par.K
+        ph, mag, inc = np.empty((b, k)), np.empty((b, k)), np.empty((b, k))
+        par._call("voc_analysis_step", _p(prev_ph), _p(spec), _p(ph), _p(mag), _p(inc), b)
+    else:
+        hop, n, prev_ph, spec = (par_or_hop,) + args
+        spec = np.ascontiguousarray(spec, dtype=np.complex128)
+        k = spec.shape[-1]
+        spec, lead = _batched(spec, k, np.complex128)
+        prev_ph, _ = _batched(prev_ph, k)
+        b = spec.shape[0]
+        ph, mag, inc = np.empty((b, k)), np.empty((b, k)), np.empty((b, k))
+        _free_call(lib, "voc_analysis_step_hn", int(hop), int(n), k, _p(prev_ph), _p(spec), _p(ph), _p(mag), _p(inc), b)
+    sh = lead + (k,)
     return ph.reshape(sh), (mag.reshape(sh), inc.reshape(sh))
 
 
-def synthesis_step(par, ph, stft):
-    """synthesisStep hop ph (mag, ph_inc) -> (new_ph, spectrum) (Vocoder.hs:186-190)."""
+def synthesis_step(par_or_hop, ph, stft, lib: Library | None = None):
+    """synthesisStep hop ph (mag, ph_inc) -> (new_ph, spectrum) (Vocoder.hs:186-190).  The first
+    argument is the hop size, as in the reference, or a `VocoderParams` whose hop size is used."""
     mag, inc = stft
-    mag, lead = _batched(mag, par.K)
-    inc, _ = _batched(inc, par.K)
-    ph, _ = _batched(ph, par.K)
+    mag = np.ascontiguousarray(mag, dtype=np.float64)
+    k = par_or_hop.K if isinstance(par_or_hop, VocoderParams) else mag.shape[-1]
+    mag, lead = _batched(mag, k)
+    inc, _ = _batched(inc, k)
+    ph, _ = _batched(ph, k)
     b = mag.shape[0]
-    out, spec = np.empty((b, par.K)), np.empty((b, par.K), dtype=np.complex128)
-    par._call("voc_synthesis_step", _p(ph), _p(mag), _p(inc), _p(out), _p(spec), b)
-    sh = lead + (par.K,)
+    out, spec = np.empty((b, k)), np.empty((b, k), dtype=np.complex128)
+    if isinstance(par_or_hop, VocoderParams):
+        par_or_hop._call("voc_synthesis_step", _p(ph), _p(mag), _p(inc), _p(out), _p(spec), b)
+    else:
+        _free_call(lib, "voc_synthesis_step_h", int(par_or_hop), k, _p(ph), _p(mag), _p(inc), _p(out), _p(spec), b)
+    sh = lead + (k,)
     return out.reshape(sh), spec.reshape(sh)
 
 
-def add_frames(par, f1, f2):
-    """addFrames (Vocoder.hs:220-222)."""
-    m1, lead = _batched(f1[0], par.K)
-    i1, _ = _batched(f1[1], par.K)
-    m2, _ = _batched(f2[0], par.K)
-    i2, _ = _batched(f2[1], par.K)
-    b = m1.shape[0]
-    mo, io = np.empty((b, par.K)), np.empty((b, par.K))
-    par._call("voc_add_frames", _p(m1), _p(i1), _p(m2), _p(i2), _p(mo), _p(io), b)
-    sh = lead + (par.K,)
-    return mo.reshape(sh), io.reshape(sh)
+def frame_from_complex(spec, lib: Library | None = None):
+    """frameFromComplex (Vocoder.hs:217-218): complex spectrum -> (mag, phase)."""
+    spec = np.ascontiguousarray(spec, dtype=np.complex128)
+    mag, ph = np.empty(spec.shape), np.empty(spec.shape)
+    _free_call(lib, "voc_frame_from_complex", _p(spec), _p(mag), _p(ph), spec.size)
+    return mag, ph
+
+
+def frame_to_complex(stft, lib: Library | None = None):
+    """frameToComplex (Vocoder.hs:213-214): (mag, phase) -> complex spectrum."""
+    mag, ph = _f64(stft[0]), _f64(stft[1])
+    if mag.shape != ph.shape:
+        raise VocoderError(-5, "size mismatch between moduli and phases")
+    spec = np.empty(mag.shape, dtype=np.complex128)
+    _free_call(lib, "voc_frame_to_complex", _p(mag), _p(ph), _p(spec), mag.size)
+    return spec
+
+
+def add_frames(*args, lib: Library | None = None):
+    """addFrames f1 f2 (Vocoder.hs:220-222); `add_frames(par, f1, f2)` is accepted too."""
+    if len(args) == 3:
+        par, f1, f2 = args
+        m1, lead = _batched(f1[0], par.K)
+        i1, _ = _batched(f1[1], par.K)
+        m2, _ = _batched(f2[0], par.K)
+        i2, _ = _batched(f2[1], par.K)
+        b = m1.shape[0]
+        mo, io = np.empty((b, par.K)), np.empty((b, par.K))
+        par._call("voc_add_frames", _p(m1), _p(i1), _p(m2), _p(i2), _p(mo), _p(io), b)
+        sh = lead + (par.K,)
+        return mo.reshape(sh), io.reshape(sh)
+    f1, f2 = args
+    arrs = [_f64(a) for a in (f1[0], f1[1], f2[0], f2[1])]
+    if any(a.shape != arrs[0].shape for a in arrs):
+        raise VocoderError(-5, "size mismatch between the frames")
+    mo, io = np.empty(arrs[0].shape), np.empty(arrs[0].shape)
+    _free_call(lib, "voc_add_frames_n", *[_p(a) for a in arrs], _p(mo), _p(io), arrs[0].size)
+    return mo, io
 
 
 def _stage_shapes(phase, data, inner):
