@@ -390,8 +390,8 @@ int32_t voc_planar_to_pcm16_dev(voc_ctx *ctx, const double *planar, int64_t stri
  * (Frames.hs:49-53); voc_stream_flush publishes the rest, zero padded to a whole chunk
  * (publishRest, Frames.hs:46-47), after which the stream only answers queries.
  *   filter       chain applied to every frame between analysis and synthesis, or NULL
- *                (idFilter); must outlive the stream.  playSpeed is not a per-frame chain
- *                and is not available in streaming form.
+ *                (idFilter); must outlive the stream.  playSpeed is not a per-frame chain:
+ *                see voc_stream_set_play_speed.
  *   x            [C][x_stride], n new samples per channel (n = 0 is allowed)
  *   y            [C][y_stride], receives *n_out <= y_cap samples per channel;
  *                voc_stream_push_length / _flush_length tell *n_out beforehand
@@ -417,6 +417,12 @@ int32_t voc_stream_create(voc_ctx *ctx, int64_t channels, int64_t chunk, voc_fil
 int32_t voc_stream_create_mode(voc_ctx *ctx, int64_t channels, int64_t chunk, voc_filter *filter, int32_t mode,
                                voc_stream **out);
 int32_t voc_stream_set_filter(voc_stream *s, voc_filter *filter);
+/* playSpeed inside the stream (Vocoder.Conduit.Filter.playSpeed, Conduit/Filter.hs:122-136): the frames that
+ * leave the stream's filter chain are repeated or dropped at the exact rational rate num / den (frame i is
+ * yielded floor((i+1) num / den) - floor(i num / den) times), and `after` (may be NULL) runs on the yielded
+ * frames, so that `chain .| playSpeed r .| chain'` is one stream.  The concatenated output equals the batch
+ * path's on the whole signal.  To be called before the first push; conduit conventions only; num, den <= 2^20. */
+int32_t voc_stream_set_play_speed(voc_stream *s, int64_t num, int64_t den, voc_filter *after);
 int32_t voc_stream_destroy(voc_stream *s);
 int32_t voc_stream_set_phases(voc_stream *s, const double *ana_phase, const double *syn_phase);
 int32_t voc_stream_get_phases(voc_stream *s, double *ana_phase, double *syn_phase);

@@ -6,6 +6,8 @@ import sys
 import numpy as np
 import pytest
 
+import helpers as Hh
+
 pytestmark = pytest.mark.gpu
 
 
@@ -151,3 +153,38 @@ def test_random_phase_stream_hop_by_hop_on_device(gpu_lib):
     y = np.concatenate([o.cpu().numpy() for o in outs] + [st.flush()], axis=1)
     assert np.array_equal(y, y_ref.cpu().numpy())
     assert np.array_equal(st.phases()[1], s_ref.cpu().numpy())
+
+
+@pytest.mark.parametrize("speed", ["2", "2/3", "1/3"])
+def test_play_speed_inside_a_stream_on_device(gpu_lib, orc, speed):
+    """chain .| playSpeed r .| chain' chunk by chunk (Conduit/Filter.hs:122-136): the batch path's bits,
+    the oracle's samples within the bar; random increments keyed by the yielded frame's position."""
+    import torch
+    from fractions import Fraction
+    from vocoder_amd import vocoder as V, conduit as Cd, stream as S, filter as Fl
+    n, hop = 4096, 1024
+    win = 0.5 * (1 - np.cos(2 * np.pi * np.arange(n) / n))
+    par = V.VocoderParams(n, hop, win, lib=gpu_lib)
+    step = 48000.0 / n
+    r = Fraction(speed)
+    x = np.random.default_rng(21).standard_normal((3, n + hop * 40 + 77))
+    xd = torch.from_numpy(x).cuda()
+    filt = (Fl.lowpass_butterworth(2.0, 6000.0) >> Fl.play_speed(r)).bind(par, step)
+    y_ref, a_ref, s_ref = Cd.process_filter_dev(par, filt, xd)
+    st = S.Stream(par, 3, filt=filt)
+    cuts = (0, 5000, 5001, 20000, x.shape[1])
+    outs = [st.push_dev(xd[:, a:b].contiguous()) for a, b in zip(cuts[:-1], cuts[1:])]
+    torch.cuda.synchronize()
+    y = np.concatenate([o.cpu().numpy() for o in outs] + [st.flush()], axis=1)
+    assert y.shape == tuple(y_ref.shape) and np.array_equal(y, y_ref.cpu().numpy())
+    a, sph = st.phases()
+    assert np.array_equal(a, a_ref.cpu().numpy()) and np.array_equal(sph, s_ref.cpu().numpy())
+    ref = Hh.oracle_filtered(orc, n, hop, win, x[2], step, [("lowpass_butterworth", (2.0, 6000.0))], speed=r)
+    assert y.shape[1] == ref["y"].size and Hh.rel_l2(y[2], ref["y"]) <= Hh.TOL_L2
+    # the same with a random-phase chain behind the speed change, host pushes
+    filt2 = (Fl.play_speed(r) >> Fl.random_phase_filter(5)).bind(par, step)
+    y2_ref, _, s2_ref = Cd.process_filter_dev(par, filt2, xd)
+    st2 = S.Stream(par, 3, filt=filt2)
+    outs2 = [st2.push(x[:, a:b]) for a, b in zip(cuts[:-1], cuts[1:])] + [st2.flush()]
+    assert np.array_equal(np.concatenate(outs2, axis=1), y2_ref.cpu().numpy())
+    assert np.array_equal(st2.phases()[1], s2_ref.cpu().numpy())

@@ -8,6 +8,8 @@ import sys
 import numpy as np
 import pytest
 
+import helpers as Hh
+
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from helpers import TOL_L2  # noqa: E402
 
@@ -121,7 +123,12 @@ def test_stream_argument_errors(emu_lib):
     with pytest.raises(V.VocoderError):
         st.push(x)                                        # a flushed stream takes no more input
     with pytest.raises(ValueError):
-        S.Stream(par, 1, filt=Fl.play_speed(2).bind(par, 1.0))
+        S.Stream(par, 1, filt=(Fl.play_speed(2) >> Fl.play_speed(2)).bind(par, 1.0))   # one play_speed at most
+    with pytest.raises(V.VocoderError):
+        S.Stream(par, 1, filt=Fl.play_speed(2).bind(par, 1.0), dunai=True)            # conduit conventions only
+    sp = S.Stream(par, 1, filt=Fl.play_speed(2).bind(par, 1.0))
+    sp.push(np.zeros((1, 100)))
+    assert d.voc_stream_set_play_speed(sp._h, 3, 2, None) == -1                       # only before the first frame
 
 
 def _oracle_dunai(orc, n, hop, window, ticks):
@@ -229,3 +236,52 @@ def test_random_phase_does_not_depend_on_the_chunking(emu_lib):
     exp = random_phase_expected(9, c, 4, par.K, position=0, first_frame=5, first_channel=3)
     assert np.array_equal(got.numpy()[..., :par.K], exp)
     assert not np.array_equal(exp[0, 0], exp[0, 1]) and not np.array_equal(exp[0, 0], exp[1, 0])
+
+
+@pytest.mark.parametrize("speed,cuts", [
+    ("2", (200, 777)), ("1/2", (64, 500, 501)), ("3/2", (333,)), ("2/3", (100, 150, 900)), ("1/5", (400,)), ("0", (300,)),
+])
+def test_play_speed_inside_a_stream_equals_the_batch_path(emu_lib, orc, speed, cuts):
+    """chain .| playSpeed r .| chain' as one stream (Conduit/Filter.hs:122-136): pushes of any sizes give
+    the batch path's samples and phases bit for bit, and the oracle's within the bars."""
+    import torch
+    from fractions import Fraction
+    from vocoder_amd import vocoder as V, conduit as Cd, stream as S, filter as Fl
+    n, hop = 128, 32
+    win = _hann(n)
+    par = V.VocoderParams(n, hop, win, lib=emu_lib)
+    step = 48000.0 / n
+    r = Fraction(speed)
+    desc = Fl.lowpass_butterworth(2.0, 6000.0) >> Fl.play_speed(r) >> Fl.amplify(0.5)
+    filt = desc.bind(par, step)
+    x = np.random.default_rng(11).standard_normal((2, n + hop * 30 + 7))
+    y_ref, a_ref, s_ref = Cd.process_filter_dev(par, filt, torch.from_numpy(x))
+    st = S.Stream(par, 2, filt=filt)
+    edges = (0,) + tuple(cuts) + (x.shape[1],)
+    outs = [st.push(x[:, a:b]) for a, b in zip(edges[:-1], edges[1:])] + [st.flush()]
+    y = np.concatenate(outs, axis=1)
+    assert y.shape == tuple(y_ref.shape) and np.array_equal(y, y_ref.numpy())
+    a, sph = st.phases()
+    assert np.array_equal(a, a_ref.numpy()) and np.array_equal(sph, s_ref.numpy())
+    ref = Hh.oracle_filtered(orc, n, hop, win, x[1], step, [("lowpass_butterworth", (2.0, 6000.0))], speed=r)
+    mag2, inc2 = orc.apply_filter(step, [("amplify", (0.5,))], ref["mag"], ref["ph_inc"]) if ref["mag"].shape[0] else (ref["mag"], ref["ph_inc"])
+    assert np.array_equal(inc2, ref["ph_inc"])            # a gain leaves the increments alone: ref["y"] scales by 0.5
+    assert y.shape[1] == ref["y"].size
+    if ref["y"].size:
+        assert Hh.rel_l2(y[1], 0.5 * ref["y"]) <= Hh.TOL_L2
+
+
+def test_random_phase_after_play_speed_in_a_stream(emu_lib):
+    """`--playSpeed 2 --randomPhase` chunk by chunk: the random increments are keyed by the position of the
+    yielded frame in the stream, so the chunking does not change them."""
+    import torch
+    from vocoder_amd import vocoder as V, conduit as Cd, stream as S, filter as Fl
+    n, hop = 128, 32
+    par = V.VocoderParams(n, hop, _hann(n), lib=emu_lib)
+    filt = (Fl.play_speed(2) >> Fl.random_phase_filter(9)).bind(par, 1.0)
+    x = np.random.default_rng(12).standard_normal((2, n + hop * 20 + 5))
+    y_ref, _, s_ref = Cd.process_filter_dev(par, filt, torch.from_numpy(x))
+    st = S.Stream(par, 2, filt=filt)
+    outs = [st.push(x[:, :130]), st.push(x[:, 130:131]), st.push(x[:, 131:600]), st.push(x[:, 600:]), st.flush()]
+    assert np.array_equal(np.concatenate(outs, axis=1), y_ref.numpy())
+    assert np.array_equal(st.phases()[1], s_ref.numpy())

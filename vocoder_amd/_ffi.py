@@ -75,6 +75,7 @@ SIGNATURES = {
     "voc_stream_create": (_i32, [_vp, _i64, _i64, _vp, C.POINTER(_vp)]),
     "voc_stream_create_mode": (_i32, [_vp, _i64, _i64, _vp, _i32, C.POINTER(_vp)]),
     "voc_stream_set_filter": (_i32, [_vp, _vp]),
+    "voc_stream_set_play_speed": (_i32, [_vp, _i64, _i64, _vp]),
     "voc_stream_destroy": (_i32, [_vp]),
     "voc_stream_set_phases": (_i32, [_vp, _vp, _vp]),
     "voc_stream_get_phases": (_i32, [_vp, _vp, _vp]),

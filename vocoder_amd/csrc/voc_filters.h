@@ -236,4 +236,24 @@ __global__ void gather_frames_kernel(const double *__restrict__ mag_in, const do
     }
 }
 
+// playSpeed on a run of frames of a longer stream (Conduit/Filter.hs:122-136): the filter yields frame i
+// floor((i+1) num / den) - floor(i num / den) times, so output frame t of the stream is input frame
+// floor(((t+1) den - 1) / num).  Output rows out_first .. out_first + G of every channel are copied from
+// the input rows held from in_first on; rows of a channel are in_rpc / out_rpc rows apart.
+__global__ void replicate_frames_kernel(const double *__restrict__ mag_in, const double *__restrict__ inc_in,
+                                        long long in_rpc, long long in_first, long long ldk, long long num, long long den,
+                                        long long out_first, long long G, double *__restrict__ mag_out,
+                                        double *__restrict__ inc_out, long long out_rpc, long long total)
+{
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const long long k = g % ldk;
+        const long long row = g / ldk;
+        const long long j = row % G, c = row / G;
+        const long long i = ((out_first + j + 1) * den - 1) / num - in_first;
+        const long long from = (c * in_rpc + i) * ldk + k, to = (c * out_rpc + j) * ldk + k;
+        mag_out[to] = mag_in[from];
+        inc_out[to] = inc_in[from];
+    }
+}
+
 }  // namespace voc

@@ -330,19 +330,23 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
     // Slot u holds the sample pair at frame positions 2 tid + 2 u T (+1).  The first FFT pass reads
     // the frame rewound (v[n] = padded[(n + N/2) mod N]) and even/odd packed: its element
     // tid + j T is slot (j + 4) mod 8.
+    // Pair loads are a uniform base (moved by whole multiples of T pairs: scalar arithmetic), one 32-bit
+    // lane offset and no more.  The lane offset comes from an opaque copy of the thread id taken where
+    // the loads are issued: derived from the thread id itself, the loop-invariant addresses are hoisted
+    // as one 64-bit pointer per load (16 registers for the window alone, and spills).
     C2 xs[8], xn[NEW], ws[8];
-    auto sample_pair = [&](const R *fr, int u) -> C2 {
-        const unsigned i0 = (unsigned)(2 * (tid + u * T));  // unsigned: SGPR base + 32-bit lane offset
-        if (VEC2) return *reinterpret_cast<const C2 *>(fr + i0);
+    auto sample_pair = [&](const R *fr, int u, int lt) -> C2 {
+        if (VEC2) return at_bytes(reinterpret_cast<const C2 *>(fr) + u * T, (unsigned)lt * (unsigned)sizeof(C2), 0);
+        const unsigned i0 = (unsigned)(2 * (lt + u * T));
         const int j0 = (int)i0 - p.hd, j1 = j0 + 1;
         return mk2((j0 >= 0 && j0 < p.W) ? fr[j0] : (R)0, (j1 >= 0 && j1 < p.W) ? fr[j1] : (R)0);
     };
-    auto load_window = [&]() {
+    auto load_window = [&](int lt) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const unsigned i0 = (unsigned)(2 * (tid + u * T));
+            const unsigned i0 = (unsigned)(2 * (lt + u * T));
             if (VEC2) {
-                ws[u] = *reinterpret_cast<const C2 *>(p.window + i0);
+                ws[u] = at_bytes(reinterpret_cast<const C2 *>(p.window) + u * T, (unsigned)lt * (unsigned)sizeof(C2), 0);
             } else {
                 const int j0 = (int)i0 - p.hd, j1 = j0 + 1;
                 ws[u] = mk2((j0 >= 0 && j0 < p.W) ? p.window[j0] : (R)0, (j1 >= 0 && j1 < p.W) ? p.window[j1] : (R)0);
@@ -355,12 +359,12 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
     {
         const R *fr = xc + fs * a.frame_stride;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) xs[u] = sample_pair(fr, u);
-        load_window();
+        for (int u = 0; u < 8; ++u) xs[u] = sample_pair(fr, u, tid);
+        load_window(tid);
     }
     for (long long f = fs; f < f1; ++f) {
         const bool emit = f >= f0;
-        if (!(VEC2 && VOC_WS_PREFETCH) && f > fs) load_window();  // predicated loads: not worth the registers of a prefetch
+        if (!(VEC2 && VOC_WS_PREFETCH) && f > fs) load_window(opaque_int(tid));  // predicated loads: not worth the registers of a prefetch
         C2 v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -371,9 +375,10 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
         fft_after_first<LOG2M>(lds, tw, tid, v, [&]() {
             if (f + 1 < f1) {  // the pairs of the next frame that are not already in registers, and the window again
                 const R *fr = xc + (f + 1) * a.frame_stride;
+                const int lp = opaque_int(tid);
 #pragma unroll
-                for (int i = 0; i < NEW; ++i) xn[i] = sample_pair(fr, 8 - NEW + i);
-                if (VEC2 && VOC_WS_PREFETCH) load_window();
+                for (int i = 0; i < NEW; ++i) xn[i] = sample_pair(fr, 8 - NEW + i, lp);
+                if (VEC2 && VOC_WS_PREFETCH) load_window(lp);
             }
         });
 
@@ -530,9 +535,11 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
     // byte offsets in a row are four per-thread values plus immediates: slot 0 has its own pair of
     // offsets, slots 1..3 sit at +-(m - 2) T elements around one offset each.
     constexpr int SZ = (int)sizeof(R);
-    const unsigned row_pe0 = (unsigned)(tid == 0 ? M / 2 : tid) * SZ, row_q0 = (unsigned)(M * SZ) - row_pe0;
-    const unsigned row_pe2 = (unsigned)(tid + 2 * T) * SZ, row_q2 = (unsigned)(M * SZ) - row_pe2;
-    auto load_row = [&](long long f, int) {
+    // (formed from the frame's opaque copy of the thread id: hoisted, they become eight 64-bit row
+    // pointers per thread that live across the whole loop)
+    auto load_row = [&](long long f, int lt) {
+        const unsigned row_pe0 = (unsigned)(lt == 0 ? M / 2 : lt) * SZ, row_q0 = (unsigned)(M * SZ) - row_pe0;
+        const unsigned row_pe2 = (unsigned)(lt + 2 * T) * SZ, row_q2 = (unsigned)(M * SZ) - row_pe2;
         const R *mrow = MAPPED ? mag_row_of(a, c, f) : a.mag + (c * a.F + f) * a.ldk;
         const R *irow = MAPPED ? inc_row_of(a, c, f) : a.inc + (c * a.F + f) * a.ldk;
         mg[0] = at_bytes(mrow, row_pe0, 0);
@@ -554,15 +561,20 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
         }
     };
 
-    if (ROW_PF) load_row(fs, tid);
+    if (ROW_PF) load_row(fs, opaque_int(tid));
     for (long long f = fs; f < f1; ++f) {
         const long long row = c * a.F + f;
         const int lt = opaque_int(tid);  // keeps this frame's index arithmetic inside the loop
         if (!ROW_PF) load_row(f, lt);
+        // m is a constant in every copy of the unrolled loop: the self-paired bin exists in the first
+        // copy only, and the LDS addresses of the other pairs are one base each plus an immediate
+        // (element e lives at e + e/8 and T is a multiple of 8)
+        const bool self0 = lt == 0;
+        C2 *zlo = lds + lds_pad(lt), *zhi = lds + lds_pad(M - lt);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            const unsigned pr = lt + m * T;
-            const unsigned pe = pr == 0 ? M / 2 : pr;
+            const bool self = m == 0 && self0;
+            const unsigned pe = self ? M / 2 : (unsigned)(lt + m * T);
             const unsigned q = M - pe;
             C2 A, B;
             if constexpr (PHASE_REGS) {
@@ -576,9 +588,14 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
                 php[q] = pb;
             }
             C2 Za, Zb;
-            merge_pair(A, B, split_tw(tw.s, m, pr == 0), Za, Zb);
-            lds[lds_pad(pe)] = Za;
-            lds[lds_pad(q)] = Zb;
+            merge_pair(A, B, split_tw(tw.s, m, self), Za, Zb);
+            if (m == 0) {
+                lds[lds_pad(pe)] = Za;
+                lds[lds_pad(q)] = Zb;
+            } else {
+                zlo[m * (T + T / 8)] = Za;
+                zhi[-m * (T + T / 8)] = Zb;
+            }
 #if VOC_SYN_FENCE
             sched_fence();  // one bin pair at a time: interleaving all eight sincos chains overflows the register budget
 #endif
@@ -607,11 +624,18 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
         const bool emit = f >= f0;
         if (OLA) {
             // W == N (off = 0): window samples 2i, 2i+1 pair with complex element (i + M/2) mod M
+            // element lt + e with e a multiple of T (of 8) sits at pad(lt) + e + e/8: one LDS base plus
+            // immediates; window and output rows: uniform bases T pairs apart plus one lane offset
             C2 wv[NP], zv[NP];
+            const unsigned lane16 = (unsigned)lt * (unsigned)sizeof(C2);
+            const C2 *zb = lds + lds_pad(lt);
 #pragma unroll
-            for (int j = 0; j < NP; ++j) wv[j] = reinterpret_cast<const C2 *>(p.window)[(unsigned)(lt + j * T)];
+            for (int j = 0; j < NP; ++j) wv[j] = at_bytes(reinterpret_cast<const C2 *>(p.window) + j * T, lane16, 0);
 #pragma unroll
-            for (int j = 0; j < NP; ++j) zv[j] = lds[lds_pad((lt + j * T + M / 2) & (M - 1))];
+            for (int j = 0; j < NP; ++j) {
+                const int e = (j * T + M / 2) & (M - 1);
+                zv[j] = zb[e + e / 8];
+            }
             C2 cur[NP];
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
@@ -622,7 +646,7 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
             if (emit) {
                 C2 *yc = reinterpret_cast<C2 *>(a.out + c * a.out_stride + f * p.H);
 #pragma unroll
-                for (int j = 0; j < NHP; ++j) yc[(unsigned)(lt + j * T)] = cur[j];
+                for (int j = 0; j < NHP; ++j) at_bytes(yc + j * T, lane16, 0) = cur[j];
             }
 #pragma unroll
             for (int j = 0; j < NK; ++j) tail[j] = cur[j + NHP];

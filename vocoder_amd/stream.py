@@ -16,22 +16,31 @@ __all__ = ["Stream"]
 class Stream:
     def __init__(self, par: VocoderParams, channels: int = 1, chunk: int | None = None, filt=None,
                  ana_phase=None, syn_phase=None, dunai: bool = False):
-        """filt: a `vocoder_amd.filter.BoundFilter` made of per-frame stages only, or None.
+        """filt: a `vocoder_amd.filter.BoundFilter`, or None: one chain of per-frame stages, optionally with
+        one play_speed stage anywhere in it (`chain >> play_speed(r) >> chain'`).
         dunai=True: the conventions of Vocoder.Dunai.process (vocoder-dunai/src/Vocoder/Dunai.hs:46-48):
         zero pre-pad, pushes in multiples of the hop, as many samples out as in."""
         self.par, self.channels = par, int(channels)
         self.chunk = par.H if chunk is None else int(chunk)
-        fh = None
+        fh, speed, after = None, None, None
         if filt is not None:
             kinds = [k for k, _ in filt.parts]
-            if kinds not in ([], ["chain"]):
-                raise ValueError("a stream takes one chain of per-frame filters (no play_speed, at most 12 stages)")
-            fh = filt.parts[0][1]._h if kinds else None
-        self._filt = filt                         # keeps the device chain alive
+            if kinds not in ([], ["chain"], ["speed"], ["chain", "speed"], ["speed", "chain"], ["chain", "speed", "chain"]):
+                raise ValueError("a stream takes chains of at most 12 per-frame filters around at most one play_speed")
+            for i, (kind, v) in enumerate(filt.parts):
+                if kind == "speed":
+                    speed = v
+                elif speed is None:
+                    fh = v._h
+                else:
+                    after = v._h
+        self._filt = filt                         # keeps the device chains alive
         h = C.c_void_p()
         par.lib.check(par.lib.dll.voc_stream_create_mode(par.handle, self.channels, self.chunk, fh, 1 if dunai else 0,
                                                          C.byref(h)), par.handle)
         self._h = h
+        if speed is not None:
+            par.lib.check(par.lib.dll.voc_stream_set_play_speed(h, speed.numerator, speed.denominator, after), par.handle)
         if ana_phase is not None or syn_phase is not None:
             a = np.zeros((self.channels, par.K)) if ana_phase is None else _f64(ana_phase).reshape(self.channels, par.K)
             s = np.zeros((self.channels, par.K)) if syn_phase is None else _f64(syn_phase).reshape(self.channels, par.K)
