@@ -56,7 +56,7 @@ struct FastCfg {
     static constexpr int K = M + 1;
     static constexpr int R4 = M / 512;               // radix of the fourth pass (1: there is none)
     static constexpr int NB4 = R4 > 1 ? 8 / R4 : 1;  // fourth-pass butterflies per thread
-    static constexpr int LDS_CPLX = Cfg<LOG2M>::LDS_CPLX;
+    static constexpr int LDS_CPLX = M;               // swizzled, not padded: see lds_sw
     static constexpr int LDS_BYTES = LDS_CPLX * 16 + ((K + 1) & ~1) * 8;  // double
     template <class R> static constexpr int lds_bytes() { return (LDS_CPLX * 2 + ((K + 1) & ~1)) * (int)sizeof(R); }
 };
@@ -87,6 +87,15 @@ VOC_DEV void merge_pair(C2 A, C2 B, C2 tw, C2 &Za, C2 &Zb)
     Za = mk2(S.y + Tw.x, S.x - Tw.y);
     Zb = mk2(Tw.x - S.y, S.x + Tw.y);
 }
+
+// Where complex element i of the transform lives in LDS: i with its low three bits XORed by the next
+// three.  A pass reads 16-byte elements that are contiguous over the lanes and writes elements that are
+// 8 (or 64, 512) apart over the lanes; the LDS serves a 16-byte read in groups of 16 lanes over 64
+// banks and a 16-byte write in groups of 8 lanes over 32 banks.  With this placement both are free of
+// bank conflicts (one spare slot per eight elements, the usual padding, leaves every read two-way
+// conflicted: a quarter of all LDS cycles), nothing is wasted on gaps, and sw(i + c) = sw(i) + c for
+// every c that is a multiple of 64, so offsets by multiples of the thread count stay immediates.
+VOC_DEV int lds_sw(int i) { return i ^ ((i >> 3) & 7); }
 
 // ---- the four Stockham passes, split into load / compute / store so that callers can place
 //      prefetches between them.  Index algebra as in fft_passes (voc_kernels.h).
@@ -179,19 +188,31 @@ template <int LOG2M, class C2>
 VOC_DEV void load8(const C2 *lds, int tid, C2 (&v)[8])
 {
     constexpr int T = FastCfg<LOG2M>::T;
-    const C2 *src = lds + lds_pad(tid);
+    const C2 *src = lds + lds_sw(tid);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = src[j * (T + T / 8)];
+    for (int j = 0; j < 8; ++j) v[j] = src[j * T];
 }
 
 template <int LOG2M, int NS, class C2>  // store of a radix-8 pass at stride NS (1, 8 or 64)
 VOC_DEV void store8(C2 *lds, int tid, const C2 (&v)[8])
 {
+    // element (tid - k) * 8 + k + j NS, k = tid mod NS.  The swizzle bits of that index are
+    // NS = 1: tid mod 8;  NS = 8: j;  NS = 64: (k / 8) mod 8 -- only the last is the same for all j.
     const int k = tid & (NS - 1);
-    C2 *dst = lds + lds_pad((tid - k) * 8 + k);
-    constexpr int STEP = NS == 1 ? 1 : NS + NS / 8;
+    if constexpr (NS == 1) {
+        C2 *dst = lds + tid * 8;
+        const int sw = tid & 7;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dst[j * STEP] = v[j];
+        for (int j = 0; j < 8; ++j) dst[j ^ sw] = v[j];
+    } else if constexpr (NS == 8) {
+        C2 *dst = lds + (tid - k) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[j * 8 + (k ^ j)] = v[j];
+    } else {
+        C2 *dst = lds + (tid - k) * 8 + lds_sw(k);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[j * NS] = v[j];
+    }
 }
 
 // v[j] *= w^j, j = 1..7
@@ -220,10 +241,10 @@ VOC_DEV void pass4_compute(const C2 *lds, int tid, const FastTw<LOG2M, C2> &t, C
         constexpr int NBF = M / R4;
 #pragma unroll
         for (int q = 0; q < FastCfg<LOG2M>::NB4; ++q) {
-            const C2 *src = lds + lds_pad(tid + q * T);
+            const C2 *src = lds + lds_sw(tid) + q * T;
             C2 w[R4];
 #pragma unroll
-            for (int j = 0; j < R4; ++j) w[j] = src[j * (NBF + NBF / 8)];
+            for (int j = 0; j < R4; ++j) w[j] = src[j * NBF];
             C2 pw = t.d[q];
             opaque(pw);
             w[1] = cmul(w[1], pw);
@@ -256,9 +277,9 @@ VOC_DEV void pass4_store(C2 *lds, int tid, const C2 (&v)[8])
         for (int q = 0; q < FastCfg<LOG2M>::NB4; ++q) {
             const int i = tid + q * T;
             const int k = i & 511;
-            C2 *dst = lds + lds_pad((i - k) * R4 + k);
+            C2 *dst = lds + (i - k) * R4 + lds_sw(k);
 #pragma unroll
-            for (int j = 0; j < R4; ++j) dst[j * 576] = v[q * R4 + j];
+            for (int j = 0; j < R4; ++j) dst[j * 512] = v[q * R4 + j];
         }
     }
 }
@@ -386,15 +407,15 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
         R *mrow = a.mag + row * a.ldk, *irow = a.inc + row * a.ldk;
         // Thread t owns the bin pairs (t + mT, M - t - mT), m = 0..3; thread 0's first pair is the
         // self-paired bin M/2.  The loop is unrolled so that m is a constant in every copy: the LDS
-        // addresses of a pair are then one per-thread base plus an immediate (element e lives at
-        // e + e/8 and T is a multiple of 8, so both bases move by whole multiples of T + T/8), the split
+        // addresses of a pair are then one per-thread base plus an immediate (lds_sw is additive in
+        // multiples of 64, and T is one, so both bases move by whole multiples of T), the split
         // twiddle's rotation is a literal, and the self-pair case exists in the first copy only.  A
         // scheduling fence after every copy keeps their live ranges apart (the register budget is
         // that of one pair).
         const int lt = opaque_int(tid);
         const bool self0 = lt == 0;
         const unsigned pe0 = self0 ? M / 2 : (unsigned)lt;      // first pair: bins pe0 and M - pe0
-        const C2 *zlo = lds + lds_pad(lt), *zhi = lds + lds_pad(M - lt);
+        const C2 *zlo = lds + lds_sw(lt), *zhi = lds + lds_sw(M - lt);
         // byte offsets of the pair's bins in an STFT row and in the phase array: slot 0 has its own, slots
         // 1..3 sit at +-(m - 2) T elements around one offset each (immediates of the memory instructions)
         constexpr int SZ = (int)sizeof(R);
@@ -408,12 +429,12 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
             const int ipe = m == 0 ? 0 : (m - 2) * T * SZ, iq = -ipe;
             C2 P, Q, w;
             if (m == 0) {
-                P = lds[lds_pad(pe)];
-                Q = lds[lds_pad(q)];
+                P = lds[lds_sw(pe)];
+                Q = lds[lds_sw(q)];
                 w = split_tw(tw.s, 0, self0);
             } else {
-                P = zlo[m * (T + T / 8)];
-                Q = zhi[-m * (T + T / 8)];
+                P = zlo[m * T];
+                Q = zhi[-m * T];
                 w = split_tw(tw.s, m, false);
             }
             C2 Xa, Xb;
@@ -440,7 +461,7 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
         // DC and Nyquist bins are real: phase 0 or pi, magnitude |x|.  Two different waves take one
         // each, so that no wave (and no SIMD) carries both on top of its four bin pairs.
         if (tid == 0 || tid == T / 2) {
-            const C2 z0 = lds[lds_pad(0)];
+            const C2 z0 = lds[0];
             const bool dc = tid == 0;
             const R xr = dc ? z0.x + z0.y : z0.x - z0.y;
             const int kb = dc ? 0 : M;
@@ -568,9 +589,9 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
         if (!ROW_PF) load_row(f, lt);
         // m is a constant in every copy of the unrolled loop: the self-paired bin exists in the first
         // copy only, and the LDS addresses of the other pairs are one base each plus an immediate
-        // (element e lives at e + e/8 and T is a multiple of 8)
+        // (lds_sw is additive in multiples of 64, and T is one)
         const bool self0 = lt == 0;
-        C2 *zlo = lds + lds_pad(lt), *zhi = lds + lds_pad(M - lt);
+        C2 *zlo = lds + lds_sw(lt), *zhi = lds + lds_sw(M - lt);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const bool self = m == 0 && self0;
@@ -590,11 +611,11 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
             C2 Za, Zb;
             merge_pair(A, B, split_tw(tw.s, m, self), Za, Zb);
             if (m == 0) {
-                lds[lds_pad(pe)] = Za;
-                lds[lds_pad(q)] = Zb;
+                lds[lds_sw(pe)] = Za;
+                lds[lds_sw(q)] = Zb;
             } else {
-                zlo[m * (T + T / 8)] = Za;
-                zhi[-m * (T + T / 8)] = Zb;
+                zlo[m * T] = Za;
+                zhi[-m * T] = Zb;
             }
 #if VOC_SYN_FENCE
             sched_fence();  // one bin pair at a time: interleaving all eight sincos chains overflows the register budget
@@ -611,7 +632,7 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
                 php[0] = ph0;
                 php[M] = phm;
             }
-            lds[lds_pad(0)] = mk2(A.x - B.x, A.x + B.x);
+            lds[0] = mk2(A.x - B.x, A.x + B.x);
         }
         __syncthreads();
         C2 v[8];
@@ -624,17 +645,17 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
         const bool emit = f >= f0;
         if (OLA) {
             // W == N (off = 0): window samples 2i, 2i+1 pair with complex element (i + M/2) mod M
-            // element lt + e with e a multiple of T (of 8) sits at pad(lt) + e + e/8: one LDS base plus
+            // element lt + e with e a multiple of T (of 64) sits at lds_sw(lt) + e: one LDS base plus
             // immediates; window and output rows: uniform bases T pairs apart plus one lane offset
             C2 wv[NP], zv[NP];
             const unsigned lane16 = (unsigned)lt * (unsigned)sizeof(C2);
-            const C2 *zb = lds + lds_pad(lt);
+            const C2 *zb = lds + lds_sw(lt);
 #pragma unroll
             for (int j = 0; j < NP; ++j) wv[j] = at_bytes(reinterpret_cast<const C2 *>(p.window) + j * T, lane16, 0);
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 const int e = (j * T + M / 2) & (M - 1);
-                zv[j] = zb[e + e / 8];
+                zv[j] = zb[e];
             }
             C2 cur[NP];
 #pragma unroll
@@ -656,7 +677,7 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
             for (int j = 0; j < 16; ++j) {
                 const int i = lt + j * T;
                 const int n = (i + p.off + M) & (N - 1);
-                const R s = ldsd[2 * lds_pad(n >> 1) + ((n & 1) ^ 1)] * p.inv_n;
+                const R s = ldsd[2 * lds_sw(n >> 1) + ((n & 1) ^ 1)] * p.inv_n;
                 if (i < p.W) fo[(unsigned)i] = p.window[(unsigned)i] * s;
             }
         }

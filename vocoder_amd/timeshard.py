@@ -180,13 +180,47 @@ def add_incoming_tail(y_local, tail):
     return y_local
 
 
-def _exchange(ops):
-    """The neighbour exchange as one batch (under RCCL the send to the next rank and the receive
-    from the previous one are grouped, so neither waits for the other to be matched first)."""
+def _through_host(t, group) -> bool:
+    """gloo carries all_gather and send / recv for host tensors only: device tensors go through host
+    copies under it (a rehearsal configuration; RCCL takes the device tensors as they are)."""
     import torch.distributed as dist
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_gather(total, world, group):
+    import torch
+    import torch.distributed as dist
+    if _through_host(total, group):
+        t = total.cpu()
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t, group=group)
+        return [o.to(total.device) for o in out]
+    out = [torch.empty_like(total) for _ in range(world)]
+    dist.all_gather(out, total, group=group)
+    return out
+
+
+def _neighbour_exchange(send, recv, rank, group):
+    """Sends `send` (or nothing, None) to the next rank and fills `recv` (or nothing) from the previous one,
+    as one batch (under RCCL the two are grouped, so neither waits for the other to be matched first)."""
+    import torch
+    import torch.distributed as dist
+
+    def peer(r):
+        return dist.get_global_rank(group, r) if group else r
+    staged = (send is not None and _through_host(send, group)) or (recv is not None and _through_host(recv, group))
+    s = send if send is None or not staged else send.cpu()
+    r = recv if recv is None or not staged else torch.empty(recv.shape, dtype=recv.dtype)
+    ops = []
+    if s is not None:
+        ops.append(dist.P2POp(dist.isend, s.contiguous(), peer(rank + 1), group))
+    if r is not None:
+        ops.append(dist.P2POp(dist.irecv, r, peer(rank - 1), group))
     if ops:
-        for r in dist.batch_isend_irecv(ops):
-            r.wait()
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    if staged and recv is not None:
+        recv.copy_(r)
 
 
 def process(par, x_seg, length: int, chunk: int | None = None, ana_phase=None, syn_phase=None, group=None):
@@ -204,25 +238,16 @@ def process(par, x_seg, length: int, chunk: int | None = None, ana_phase=None, s
     sp = plan(par, length, world, rank, chunk)
     mag, inc, aph = analyse(par, sp, x_seg, ana_phase)
     total = local_advance(par, inc)
-    if world > 1:
-        totals = [torch.empty_like(total) for _ in range(world)]
-        dist.all_gather(totals, total, group=group)
-    else:
-        totals = [total]
+    totals = _all_gather(total, world, group) if world > 1 else [total]
     y, sph = synthesise(par, sp, mag, inc, start_phase(totals, rank, syn_phase))
     if world > 1:
-        ops = []
         tail_in = None
-        if sp.tail:
-            send = y[:, sp.out_hi - sp.out_lo:].contiguous()
-            ops.append(dist.P2POp(dist.isend, send, dist.get_global_rank(group, rank + 1) if group else rank + 1, group))
+        send = y[:, sp.out_hi - sp.out_lo:].contiguous() if sp.tail else None
         if rank > 0:
             prev = plan(par, length, world, rank - 1, chunk)
             if prev.tail:
                 tail_in = torch.empty((y.shape[0], prev.tail), dtype=torch.float64, device=y.device)
-                ops.append(dist.P2POp(dist.irecv, tail_in, dist.get_global_rank(group, rank - 1) if group else rank - 1,
-                                      group))
-        _exchange(ops)
+        _neighbour_exchange(send, tail_in, rank, group)
         if tail_in is not None:
             add_incoming_tail(y, tail_in)
         last = dist.get_global_rank(group, world - 1) if group else world - 1
@@ -327,8 +352,9 @@ def process_pieces(par, source, length: int, piece_frames: int, sink=None, filt=
                 total = torch.zeros((inc.shape[0], par.K), dtype=torch.float64, device=inc.device)
             par._call("voc_phase_advance_dev", _ptr(inc), inc.shape[2], inc.shape[1], inc.shape[0], _ptr(total),
                       _stream(inc))
-        totals = [torch.empty_like(total) for _ in range(world)]
-        _timed(stats, lambda: dist.all_gather(totals, total, group=group), total.device)
+        gathered = []
+        _timed(stats, lambda: gathered.extend(_all_gather(total, world, group)), total.device)
+        totals = gathered
     else:
         totals = None
 
@@ -360,15 +386,8 @@ def process_pieces(par, source, length: int, piece_frames: int, sink=None, filt=
         del mag, inc, y
 
     if world > 1:
-        ops = []
-        if sp.tail:
-            ops.append(dist.P2POp(dist.isend, tail.contiguous(), dist.get_global_rank(group, rank + 1) if group else rank + 1,
-                                  group))
-        tail_in = None
-        if prev_tail:
-            tail_in = torch.empty_like(held)
-            ops.append(dist.P2POp(dist.irecv, tail_in, dist.get_global_rank(group, rank - 1) if group else rank - 1, group))
-        _timed(stats, lambda: _exchange(ops), carried.device)
+        tail_in = torch.empty_like(held) if prev_tail else None
+        _timed(stats, lambda: _neighbour_exchange(tail if sp.tail else None, tail_in, rank, group), carried.device)
         if tail_in is not None:
             held = tail_in + held
             if collected is not None:
