@@ -17,8 +17,9 @@
  *     {re, im} (16 bytes), the layout of Haskell's `Storable (Complex Double)`.
  *   - N = FFT frame length (vocFrameLength), W = window / input frame length
  *     (vocInputFrameLength, W <= N), H = hop (vocHopSize), K = N/2+1
- *     (vocFreqFrameLength).  This build supports N = 2^m, 8 <= N <= 16384,
- *     and every other N in [2, 4096] (chirp-z transform; double precision only).
+ *     (vocFreqFrameLength).  This build supports every N in [2, 16384]: powers of
+ *     two from 8 on directly, every other length as a chirp-z transform (double precision
+ *     only; above 4096 through device memory, an order of magnitude slower).
  *   - the caller owns every buffer; the library owns only the opaque voc_ctx.
  *   - entry points without a `_dev` suffix take HOST pointers and copy through
  *     device memory they allocate; `_dev` entry points take DEVICE pointers and

@@ -43,7 +43,7 @@ def test_status_strings_and_argument_checks_without_a_gpu():
     w = (ctypes.c_double * 16)(*([1.0] * 16))
     # argument errors are reported before any device is touched
     assert lib.dll.voc_ctx_create(8, 2, w, 16, 0, 0, ctypes.byref(h)) == -1      # W > N (Vocoder.hs:132)
-    assert lib.dll.voc_ctx_create(5000, 2, w, 16, 0, 0, ctypes.byref(h)) == -2   # neither a power of two nor <= 4096
+    assert lib.dll.voc_ctx_create(20000, 2, w, 16, 0, 0, ctypes.byref(h)) == -2  # above 16384
     assert lib.dll.voc_ctx_create(32768, 2, w, 16, 0, 0, ctypes.byref(h)) == -2  # power of two above 16384
     assert lib.dll.voc_ctx_create(12, 2, w, 12, 0, 1, ctypes.byref(h)) == -2     # single precision: powers of two only
     assert lib.dll.voc_ctx_create(16, 0, w, 16, 0, 0, ctypes.byref(h)) == -1     # hop < 1

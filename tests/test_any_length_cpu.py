@@ -24,6 +24,14 @@ def test_stages_and_roundtrip_any_length(emu_lib, orc, n, w, h):
     Hh.check_roundtrip(emu_lib, orc, n, w, h, w + h * 9 + 5, 2, rng, ana_tile=4, syn_tile=3)
 
 
+def test_length_above_4096_runs_through_device_memory(emu_lib, orc):
+    """Above 4096 the chirp-z transform is cut into interleaved 8192-point transforms (index logic only here:
+    one small case; the sizes proper are GPU tests)."""
+    rng = np.random.default_rng(5)
+    Hh.check_fft_layer(emu_lib, orc, 4100, 4100, 1025, rng)
+    Hh.check_stages(emu_lib, orc, 4100, 3000, 1000, 3, 1, rng)
+
+
 def test_filters_and_stream_on_a_non_power_of_two_length(emu_lib, orc):
     from vocoder_amd import vocoder as V, conduit as Cd, stream as S, filter as Fl
     n, h = 100, 25

@@ -233,12 +233,38 @@ def test_device_entry_matches_host_entry_and_runs_the_native_library(gpu_lib, or
 @pytest.mark.parametrize("n,w,h", [(1000, 1000, 250), (1500, 1200, 300), (3000, 3000, 750), (4093, 4093, 1023),
                                    (4095, 3001, 1000), (12, 12, 3), (7, 5, 2)])
 def test_lengths_that_are_not_powers_of_two(gpu_lib, orc, n, w, h):
-    """The chirp-z path (any frame length up to 4096, as FFTW accepts) against the oracle's long
+    """The chirp-z path in LDS (any frame length up to 4096, as FFTW accepts) against the oracle's long
     double DFT."""
     rng = np.random.default_rng(n)
     Hh.check_fft_layer(gpu_lib, orc, n, w, h, rng)
     Hh.check_stages(gpu_lib, orc, n, w, h, 5, 2, rng)
     Hh.check_roundtrip(gpu_lib, orc, n, w, h, w + h * 7 + 3, 2, rng)
+
+
+@pytest.mark.parametrize("n,w,h,f,c", [(5000, 5000, 1250, 4, 2), (6000, 4800, 1500, 3, 2), (8191, 8191, 2048, 3, 1),
+                                       (9001, 7000, 2000, 3, 2), (12000, 12000, 3000, 2, 1), (16383, 16383, 4096, 2, 1)])
+def test_lengths_above_4096_that_are_not_powers_of_two(gpu_lib, orc, n, w, h, f, c):
+    """The chirp-z transform through device memory (2 or 4 interleaved 8192-point transforms per frame) against
+    the oracle's long double DFT: FFT layer, stages, fused round trip, a stream and a filter chain."""
+    from vocoder_amd import vocoder as V, conduit as Cd, stream as S, filter as Fl
+    rng = np.random.default_rng(n)
+    Hh.check_fft_layer(gpu_lib, orc, n, w, h, rng)
+    Hh.check_stages(gpu_lib, orc, n, w, h, f, c, rng)
+    Hh.check_roundtrip(gpu_lib, orc, n, w, h, w + h * f + 3, c, rng)
+    if n == 9001:
+        win = orc.make_window("hann", w)
+        par = V.VocoderParams(n, h, win, lib=gpu_lib)
+        mag, inc = rng.uniform(0, 1, (2, 3, par.K)), rng.uniform(-1, 1, (2, 3, par.K))
+        chain = Fl.pitch_shift_interpolate(1.5) >> Fl.lowpass_butterworth(2.0, 5000.0)
+        m, i = chain.bind(par, 48000.0 / n).apply(mag, inc)
+        mo, io = orc.apply_filter(48000.0 / n, [("pitch_shift", 1.5), ("lowpass_butterworth", 2.0, 5000.0)], mag, inc)
+        assert np.allclose(m, mo, rtol=1e-12, atol=1e-15) and np.array_equal(i, io)
+        x = rng.standard_normal((2, w + h * 9 + 2))
+        y_ref = Cd.process_with(par, x)[0]
+        st = S.Stream(par, 2)
+        y = np.concatenate([st.push(x[:, :7777]), st.push(x[:, 7777:]), st.flush()], axis=1)
+        assert np.array_equal(y, y_ref)
+        par.close()
 
 
 def test_interleaved_layout_on_device(gpu_lib, orc):

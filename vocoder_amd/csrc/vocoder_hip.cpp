@@ -22,6 +22,7 @@
 #include "voc_kernels_fast.h"
 #include "voc_filters.h"
 #include "voc_kernels_bluestein.h"
+#include "voc_kernels_bluestein_big.h"
 
 #define VOC_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -69,6 +70,13 @@ struct voc_ctx {
     bool bluestein = false;
     double2 *d_chirp = nullptr, *d_bfft = nullptr;
     voc::BlueTab blue{};
+    // ... and above 4096 the chirp-z transform runs through device memory (M = 8192: the transform of each of
+    // its L1 interleaved sequences); big_ws holds the frames in flight, grow-only
+    bool blue_big = false;
+    double2 *d_wl = nullptr;
+    voc::BlueBigTab big{};
+    void *big_ws = nullptr;
+    size_t big_ws_bytes = 0;
     // single-precision contexts: float copies of the tables (the double ones stay for the accessors)
     float *d_window_f = nullptr;
     float2 *d_twP_f = nullptr, *d_twS_f = nullptr;
@@ -349,6 +357,116 @@ template <> const voc::ParamsT<float> &params_of<float>(const voc_ctx *c) { retu
 #define VOC_FOR_EACH_BLUE_LOG2L(X) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
 #endif
 
+inline unsigned ew_grid(long long total);
+
+// ---- chirp-z transform through device memory (voc_kernels_bluestein_big.h) ----------------------------
+
+// frames per pass: the transform buffer takes 16 L bytes per frame (0.25 - 0.5 MiB)
+inline long long big_blue_batch(voc_ctx *c, long long frames, size_t per_frame_extra)
+{
+    const size_t per_frame = (size_t)c->big.L1 * voc::kBigP * sizeof(double2) + per_frame_extra;
+    long long nb = (long long)(((size_t)256 << 20) / per_frame);
+    nb = nb < 1 ? 1 : nb;
+    nb = nb < frames ? nb : frames;
+    const size_t need = (size_t)nb * per_frame;
+    if (need > c->big_ws_bytes) {
+        HIPCHK(hipDeviceSynchronize());
+        if (c->big_ws) (void)hipFree(c->big_ws);
+        c->big_ws = nullptr;
+        c->big_ws_bytes = 0;
+        HIPCHK(hipMalloc(&c->big_ws, need));
+        c->big_ws_bytes = need;
+    }
+    return nb;
+}
+
+template <int SRC, int DST>
+void big_blue_transform(voc_ctx *c, const voc::BigSrc &s, const voc::BigDst &d, long long n, double2 *u, hipStream_t st)
+{
+    const unsigned grid = (unsigned)(n * c->big.L1);
+    hipLaunchKernelGGL((voc::blue_big_first_kernel<SRC>), dim3(grid), dim3(voc::Cfg<voc::kBigLog2P>::T), lds_bytes<double>(c, false),
+                       st, c->params, c->big, s, u);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(voc::blue_big_middle_kernel, dim3(ew_grid(n * voc::kBigP)), dim3(256), 0, st, c->big, u, n);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL((voc::blue_big_last_kernel<DST>), dim3(grid), dim3(voc::Cfg<voc::kBigLog2P>::T), lds_bytes<double>(c, false),
+                       st, c->params, c->big, (const double2 *)u, d);
+    HIPCHK(hipGetLastError());
+}
+
+// The contract of analysis_blue_kernel (tiles are an internal matter there; here the frames of a channel
+// are walked in order from phase_in).
+template <bool RAW, bool SPEC>
+void big_blue_analysis(voc_ctx *c, const voc::AnaArgs &a, long long channels, hipStream_t st)
+{
+    const long long total = channels * a.F;
+    if (total <= 0) return;
+    const size_t spec_bytes = SPEC ? 0 : (size_t)c->K * sizeof(double2);
+    const long long nb = big_blue_batch(c, total, spec_bytes);
+    double2 *u = static_cast<double2 *>(c->big_ws);
+    double *spec_tmp = reinterpret_cast<double *>(u + (size_t)nb * c->big.L1 * voc::kBigP);
+    if (!SPEC && a.phase_out != a.phase_in)
+        HIPCHK(hipMemcpyAsync(a.phase_out, a.phase_in, sizeof(double) * (size_t)(channels * c->K), hipMemcpyDeviceToDevice, st));
+    for (long long b0 = 0; b0 < total; b0 += nb) {
+        const long long n = total - b0 < nb ? total - b0 : nb;
+        voc::BigSrc s{a.x, a.chan_stride, a.frame_stride, nullptr, a.F, b0, 0};
+        voc::BigDst d{};
+        d.first = b0;
+        d.F = a.F;
+        if (SPEC) {
+            d.spec = a.spec;
+            d.rpc = a.rpc;
+            d.row_base = 0;
+        } else {
+            d.spec = spec_tmp;
+            d.rpc = a.F;
+            d.row_base = b0;
+        }
+        big_blue_transform<RAW ? voc::BIG_SRC_RAW : voc::BIG_SRC_FRAME, voc::BIG_DST_SPEC>(c, s, d, n, u, st);
+        if (!SPEC) {
+            hipLaunchKernelGGL(voc::spec_rows_to_polar_kernel, dim3(ew_grid(channels * c->K)), dim3(256), 0, st, c->params,
+                               c->big.n_d, (const double *)spec_tmp, b0, a.phase_out, a.mag, a.inc, a.ldk, a.rpc, a.F, b0,
+                               b0 + n, a.vol, channels);
+            HIPCHK(hipGetLastError());
+        }
+    }
+}
+
+template <int IN_MODE, int OUT_MODE>
+void big_blue_synthesis(voc_ctx *c, const voc::SynArgs &a, long long channels, hipStream_t st)
+{
+    const long long total = channels * a.F;
+    if (total <= 0) return;
+    constexpr bool POLAR = IN_MODE == voc::SYN_IN_POLAR;
+    const size_t spec_bytes = POLAR ? (size_t)c->K * sizeof(double2) : 0;
+    const long long nb = big_blue_batch(c, total, spec_bytes);
+    double2 *u = static_cast<double2 *>(c->big_ws);
+    double *spec_tmp = reinterpret_cast<double *>(u + (size_t)nb * c->big.L1 * voc::kBigP);
+    if (POLAR && a.phase_out != a.phase_in)
+        HIPCHK(hipMemcpyAsync(a.phase_out, a.phase_in, sizeof(double) * (size_t)(channels * c->K), hipMemcpyDeviceToDevice, st));
+    for (long long b0 = 0; b0 < total; b0 += nb) {
+        const long long n = total - b0 < nb ? total - b0 : nb;
+        voc::BigSrc s{nullptr, 0, 0, nullptr, a.F, b0, 0};
+        if (POLAR) {
+            hipLaunchKernelGGL(voc::polar_rows_to_spec_kernel, dim3(ew_grid(channels * c->K)), dim3(256), 0, st, c->params, a,
+                               a.phase_out, spec_tmp, b0, b0, b0 + n, channels);
+            HIPCHK(hipGetLastError());
+            s.spec = spec_tmp;
+            s.spec_base = b0;
+        } else {
+            s.spec = a.spec;
+            s.spec_base = 0;
+        }
+        voc::BigDst d{};
+        d.out = a.out;
+        d.first = b0;
+        d.F = a.F;
+        d.rpc = a.F;
+        d.row_base = 0;
+        big_blue_transform<voc::BIG_SRC_SPEC, OUT_MODE == voc::SYN_OUT_RAW ? voc::BIG_DST_RAW : voc::BIG_DST_FRAME>(c, s, d, n, u, st);
+    }
+}
+
 template <bool RAW, bool SPEC, class R = double>
 void launch_analysis(voc_ctx *c, const voc::AnaArgsT<R> &a, long long channels, hipStream_t st)
 {
@@ -358,6 +476,10 @@ void launch_analysis(voc_ctx *c, const voc::AnaArgsT<R> &a, long long channels, 
     LaunchTimer timer(c, SPEC ? KIND_OTHER : KIND_ANALYSIS, st);
     if (c->bluestein) {
         if constexpr (std::is_same<R, double>::value) {
+            if (c->blue_big) {
+                big_blue_analysis<RAW, SPEC>(c, a, channels, st);
+                return;
+            }
             switch (c->log2m) {
 #define X(L)                                                                                              \
     case L:                                                                                               \
@@ -394,6 +516,10 @@ void launch_synthesis(voc_ctx *c, const voc::SynArgsT<R> &a, long long channels,
     LaunchTimer timer(c, IN_MODE == voc::SYN_IN_SPEC ? KIND_OTHER : KIND_SYNTHESIS, st);
     if (c->bluestein) {
         if constexpr (std::is_same<R, double>::value && OUT_MODE != voc::SYN_OUT_OLA) {
+            if (c->blue_big) {
+                big_blue_synthesis<IN_MODE, OUT_MODE>(c, a, channels, st);
+                return;
+            }
             switch (c->log2m) {
 #define X(L)                                                                                              \
     case L:                                                                                               \
@@ -989,7 +1115,7 @@ VOC_EXPORT const char *voc_strerror(int32_t s)
     switch (s) {
     case VOC_OK: return "ok";
     case VOC_ERR_INVALID: return "invalid argument";
-    case VOC_ERR_UNSUPPORTED: return "unsupported frame length or precision (frame length: a power of two up to 16384, or any length up to 4096)";
+    case VOC_ERR_UNSUPPORTED: return "unsupported frame length or precision (frame length: 2 to 16384; single precision: powers of two from 8)";
     case VOC_ERR_HIP: return "HIP runtime call failed";
     case VOC_ERR_NOMEM: return "out of memory";
     case VOC_ERR_SIZE: return "size mismatch";
@@ -1010,7 +1136,8 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
     if (W > N) return VOC_ERR_INVALID;  // addZeroPadding: input longer than target length (Vocoder.hs:132)
     if (precision != VOC_PRECISION_F64 && precision != VOC_PRECISION_F32) return VOC_ERR_UNSUPPORTED;
     const bool pow2 = N >= 8 && N <= 16384 && (N & (N - 1)) == 0;
-    const bool chirp = !pow2 && N >= 2 && N <= 4096 && precision == VOC_PRECISION_F64;
+    const bool chirp = !pow2 && N >= 2 && N <= 16384 && precision == VOC_PRECISION_F64;
+    const bool chirp_big = chirp && N > 4096;  // its transform no longer fits in LDS
     if (!pow2 && !chirp) return VOC_ERR_UNSUPPORTED;
     voc_ctx *c = new (std::nothrow) voc_ctx;
     if (!c) return VOC_ERR_NOMEM;
@@ -1025,9 +1152,13 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
         HIPCHK(hipGetSymbolAddress(&c->static_scratch, HIP_SYMBOL(voc_static_scratch)));
         c->N = N; c->W = W; c->H = H; c->K = N / 2 + 1; c->M = N / 2; c->device = device;
         c->bluestein = chirp;
-        if (chirp) {  // the FFT underneath has L = 2^m >= 2N - 1 complex points
-            c->M = 8;
-            while (c->M < 2 * N - 1) c->M *= 2;
+        c->blue_big = chirp_big;
+        int chirp_len = 0;  // L = 2^m >= 2N - 1 complex points of the convolution
+        if (chirp) {
+            chirp_len = 8;
+            while (chirp_len < 2 * N - 1) chirp_len *= 2;
+            // the LDS-resident FFT underneath: all of it, or each of L / 8192 interleaved sequences
+            c->M = chirp_big ? voc::kBigP : chirp_len;
         }
         c->precision = precision;
         c->log2m = 0;
@@ -1083,7 +1214,7 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
         p.twP = c->d_twP;
         p.twS = c->d_twS;
         if (chirp) {
-            const int L = c->M;
+            const int L = chirp_len;
             const long double pi_l = 3.141592653589793238462643383279502884L;
             std::vector<double2> w((size_t)N);
             std::vector<std::complex<long double>> bl((size_t)L, std::complex<long double>(0.0L, 0.0L));
@@ -1122,6 +1253,21 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
             c->blue.bfft = c->d_bfft;
             c->blue.inv_l = 1.0 / (double)L;
             c->blue.n_d = (double)N;
+            if (chirp_big) {
+                std::vector<double2> wl((size_t)L);
+                for (int m = 0; m < L; ++m) {
+                    const long double ang = two_pi * (long double)m / (long double)L;
+                    wl[m] = make_double2((double)cosl(ang), (double)-sinl(ang));
+                }
+                HIPCHK(hipMalloc((void **)&c->d_wl, sizeof(double2) * wl.size()));
+                HIPCHK(hipMemcpy(c->d_wl, wl.data(), sizeof(double2) * wl.size(), hipMemcpyHostToDevice));
+                c->big.chirp = c->d_chirp;
+                c->big.bfft = c->d_bfft;
+                c->big.wl = c->d_wl;
+                c->big.inv_l = c->blue.inv_l;
+                c->big.n_d = c->blue.n_d;
+                c->big.L1 = L / voc::kBigP;
+            }
         }
         if (precision == VOC_PRECISION_F32) {
             // the same tables rounded once to float (twiddles from the long double values, not from the doubles)
@@ -1180,6 +1326,8 @@ VOC_EXPORT int32_t voc_ctx_destroy(voc_ctx *c)
     if (c->d_twS) (void)hipFree(c->d_twS);
     if (c->d_chirp) (void)hipFree(c->d_chirp);
     if (c->d_bfft) (void)hipFree(c->d_bfft);
+    if (c->d_wl) (void)hipFree(c->d_wl);
+    if (c->big_ws) (void)hipFree(c->big_ws);
     if (c->d_window_f) (void)hipFree(c->d_window_f);
     if (c->d_twP_f) (void)hipFree(c->d_twP_f);
     if (c->d_twS_f) (void)hipFree(c->d_twS_f);
