@@ -38,7 +38,7 @@ def test_status_strings_and_argument_checks_without_a_gpu():
     from vocoder_amd._ffi import Library
     lib = Library()
     assert lib.dll.voc_strerror(0) == b"ok"
-    assert b"power of two" in lib.dll.voc_strerror(-2)
+    assert b"2 to 16384" in lib.dll.voc_strerror(-2)
     h = ctypes.c_void_p()
     w = (ctypes.c_double * 16)(*([1.0] * 16))
     # argument errors are reported before any device is touched
