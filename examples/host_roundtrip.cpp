@@ -59,5 +59,40 @@ int main()
     double ferr = 0;
     for (int64_t i = n; i < len - 2 * n; ++i) ferr = std::fmax(ferr, std::fabs(y2[i] - 0.5 * x[i]));
     std::printf("lowpass 1000 Hz + amplify 0.5: max |y - x/2| = %.3g\n", ferr);
-    return (err < 1e-9 && diff < 1e-12 && same && ferr < 1e-3) ? 0 : 1;
+
+    // the reference's frame-level functions, with its own argument lists (Vocoder.hs:143-222): one frame by hand
+    const vocoder::Frame fr0(x.begin(), x.begin() + n), fr1(x.begin() + h, x.begin() + h + n);
+    auto [ph0, st0] = vocoder::analysisStep(h, n, par.zeroPhase(), vocoder::doFFT(par, fr0));
+    auto [ph1, st1] = vocoder::analysisStep(h, n, ph0, vocoder::doFFT(par, fr1));
+    double step_diff = 0;  // against the stage call above (before its volumeFix and filter: recompute)
+    auto [aph2, stft2] = vocoder::analysisStage(par, par.zeroPhase(), std::vector<double>(frames.begin(), frames.begin() + 2 * n));
+    double top = 0;
+    for (double m : st1.first) top = std::fmax(top, m);
+    for (size_t k = 0; k < st1.first.size(); ++k) {
+        step_diff = std::fmax(step_diff, std::fabs(st1.first[k] - stft2.mag[st1.first.size() + k]));
+        // (the phase of a bin in the leakage floor depends on the last bits of the transform, and the two paths
+        //  factor their transforms differently)
+        if (st1.first[k] > 1e-3 * top)
+            step_diff = std::fmax(step_diff, std::fabs(st1.second[k] - stft2.ph_inc[st1.first.size() + k]));
+    }
+    auto [nph, spec1] = vocoder::synthesisStep(h, par.zeroPhase(), st0);
+    const vocoder::Frame back = vocoder::doIFFT(par, spec1);
+    const auto polar = vocoder::frameFromComplex(vocoder::frameToComplex(st0));
+    double polar_diff = 0;
+    for (size_t k = 0; k < polar.first.size(); ++k) polar_diff = std::fmax(polar_diff, std::fabs(polar.first[k] - st0.first[k]));
+    const auto doubled = vocoder::addFrames(st0, st0);
+    double add_diff = 0;
+    for (size_t k = 0; k < doubled.first.size(); ++k) add_diff = std::fmax(add_diff, std::fabs(doubled.first[k] - 2 * st0.first[k]));
+    std::printf("step functions vs stage call: %.3g; polar round trip: %.3g; addFrames f f = 2 |f|: %.3g; frame of %zu samples back\n",
+                step_diff, polar_diff, add_diff, back.size());
+
+    // playSpeed 2 inside a stream: twice the frames, twice the samples
+    vocoder::Stream fast(par, 1, h);
+    fast.playSpeed(2, 1);
+    auto y2x = fast.push(x);
+    auto y2r = fast.flush();
+    std::printf("playSpeed 2 in a stream: %zu samples out for %lld in\n", y2x.size() + y2r.size(), (long long)len);
+    const bool speed_ok = y2x.size() + y2r.size() > (size_t)(2 * (len - 2 * n));
+    return (err < 1e-9 && diff < 1e-12 && same && ferr < 1e-3 && step_diff < 1e-12 && polar_diff < 1e-12 && add_diff < 1e-12 &&
+            speed_ok) ? 0 : 1;
 }

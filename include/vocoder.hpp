@@ -6,6 +6,7 @@
 // failing call throws std::runtime_error where the reference calls `error` (Vocoder.hs:132).
 #pragma once
 
+#include <complex>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -21,6 +22,10 @@ using Window = Frame;                  // Vocoder.hs:68
 using Phase = std::vector<double>;     // Vocoder.hs:57
 using Moduli = std::vector<double>;    // Vocoder.hs:54
 using PhaseInc = std::vector<double>;  // Vocoder.hs:62
+using HopSize = int;                   // Vocoder.hs:71
+using Length = int;                    // Vocoder.hs:74
+using STFTFrame = std::pair<Moduli, PhaseInc>;          // Vocoder.hs:77
+using FFTOutput = std::vector<std::complex<double>>;    // Vocoder.hs:80; {re, im} pairs, the library's layout
 struct STFTFrames {                    // a run of STFTFrame = (Moduli, PhaseInc), Vocoder.hs:77, F x K each
     std::vector<double> mag, ph_inc;
 };
@@ -51,11 +56,91 @@ public:
     int vocHopSize() const { return voc_hop_size(ctx_); }                     // Vocoder.hs:95
     double volumeCoeff() const { return voc_volume_coeff(ctx_); }             // Vocoder.hs:209-210
     Phase zeroPhase() const { return Phase((size_t)vocFreqFrameLength(), 0.0); }  // Vocoder.hs:204-205
+    Window vocWindow() const                                                   // Vocoder.hs:97
+    {
+        Window w((size_t)vocInputFrameLength());
+        check(voc_window(ctx_, w.data()), "vocWindow");
+        return w;
+    }
     voc_ctx *handle() const { return ctx_; }
 
 private:
     voc_ctx *ctx_ = nullptr;
 };
+
+// doFFT par frame (Vocoder.hs:143-145): window, zero padding, rewind, real-to-complex transform
+inline FFTOutput doFFT(const VocoderParams &par, const Frame &frame)
+{
+    if (frame.size() != (size_t)par.vocInputFrameLength()) throw std::runtime_error("doFFT: size mismatch");
+    FFTOutput out((size_t)par.vocFreqFrameLength());
+    check(voc_do_fft(par.handle(), frame.data(), reinterpret_cast<double *>(out.data()), 1), "doFFT", par.handle());
+    return out;
+}
+
+// doIFFT par spectrum (Vocoder.hs:194-196): complex-to-real transform, rewind, cutCenter, window
+inline Frame doIFFT(const VocoderParams &par, const FFTOutput &spec)
+{
+    if (spec.size() != (size_t)par.vocFreqFrameLength()) throw std::runtime_error("doIFFT: size mismatch");
+    Frame out((size_t)par.vocInputFrameLength());
+    check(voc_do_ifft(par.handle(), reinterpret_cast<const double *>(spec.data()), out.data(), 1), "doIFFT", par.handle());
+    return out;
+}
+
+// analysisStep h eN prev_ph vec -> (ph, (mag, ph_inc))  (Vocoder.hs:158-163): no VocoderParams, as in the reference
+inline std::pair<Phase, STFTFrame> analysisStep(HopSize h, Length eN, const Phase &prev_ph, const FFTOutput &vec)
+{
+    if (prev_ph.size() != vec.size()) throw std::runtime_error("analysisStep: size mismatch");
+    const size_t k = vec.size();
+    Phase ph(k);
+    STFTFrame fr{Moduli(k), PhaseInc(k)};
+    check(voc_analysis_step_hn(h, eN, (int64_t)k, prev_ph.data(), reinterpret_cast<const double *>(vec.data()), ph.data(),
+                               fr.first.data(), fr.second.data(), 1),
+          "analysisStep");
+    return {std::move(ph), std::move(fr)};
+}
+
+// synthesisStep hop ph (mag, ph_inc) -> (new_ph, spectrum)  (Vocoder.hs:186-190)
+inline std::pair<Phase, FFTOutput> synthesisStep(HopSize hop, const Phase &ph, const STFTFrame &fr)
+{
+    const size_t k = ph.size();
+    if (fr.first.size() != k || fr.second.size() != k) throw std::runtime_error("synthesisStep: size mismatch");
+    Phase out(k);
+    FFTOutput spec(k);
+    check(voc_synthesis_step_h(hop, (int64_t)k, ph.data(), fr.first.data(), fr.second.data(), out.data(),
+                               reinterpret_cast<double *>(spec.data()), 1),
+          "synthesisStep");
+    return {std::move(out), std::move(spec)};
+}
+
+// frameFromComplex / frameToComplex (Vocoder.hs:217-218, 213-214)
+inline STFTFrame frameFromComplex(const FFTOutput &vec)
+{
+    STFTFrame fr{Moduli(vec.size()), Phase(vec.size())};
+    check(voc_frame_from_complex(reinterpret_cast<const double *>(vec.data()), fr.first.data(), fr.second.data(),
+                                 (int64_t)vec.size()),
+          "frameFromComplex");
+    return fr;
+}
+inline FFTOutput frameToComplex(const STFTFrame &fr)
+{
+    if (fr.first.size() != fr.second.size()) throw std::runtime_error("frameToComplex: size mismatch");
+    FFTOutput out(fr.first.size());
+    check(voc_frame_to_complex(fr.first.data(), fr.second.data(), reinterpret_cast<double *>(out.data()), (int64_t)out.size()),
+          "frameToComplex");
+    return out;
+}
+
+// addFrames f1 f2 (Vocoder.hs:220-222)
+inline STFTFrame addFrames(const STFTFrame &f1, const STFTFrame &f2)
+{
+    const size_t k = f1.first.size();
+    if (f1.second.size() != k || f2.first.size() != k || f2.second.size() != k) throw std::runtime_error("addFrames: size mismatch");
+    STFTFrame out{Moduli(k), PhaseInc(k)};
+    check(voc_add_frames_n(f1.first.data(), f1.second.data(), f2.first.data(), f2.second.data(), out.first.data(),
+                           out.second.data(), (int64_t)k),
+          "addFrames");
+    return out;
+}
 
 // analysisStage par ph frames -> (ph', stft)  (Vocoder.hs:149-150); frames is F x W, row major
 inline std::pair<Phase, STFTFrames> analysisStage(const VocoderParams &par, Phase ph, const std::vector<double> &frames)
@@ -170,6 +255,12 @@ public:
     ~Stream() { voc_stream_destroy(s_); }
     Stream(const Stream &) = delete;
     Stream &operator=(const Stream &) = delete;
+
+    // playSpeed num/den between the stream's chain and `after` (Conduit/Filter.hs:122-136); before the first push
+    void playSpeed(int64_t num, int64_t den, const Filter *after = nullptr)
+    {
+        check(voc_stream_set_play_speed(s_, num, den, after ? after->handle() : nullptr), "playSpeed", par_.handle());
+    }
 
     // x: channels x n planar; returns channels x m planar
     std::vector<double> push(const std::vector<double> &x)
