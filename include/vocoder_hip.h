@@ -223,7 +223,9 @@ int32_t voc_roundtrip_dev(voc_ctx *ctx, const double *x, int64_t x_stride, int64
  * VOC_ERR_SCRATCH and touches nothing (N = 4096, H = 1024: about 2000 frames per channel,
  * 43 s at 48 kHz).  Every call on one GPU, from any context or thread, uses that GPU's one
  * array: calls that overlap in time on one GPU race; order them on one HIP stream or
- * synchronise between them.  Nothing in the array has to be cleared between calls.
+ * synchronise between them.  Nothing in the array has to be cleared between calls.  Frame lengths
+ * above 4096 that are not powers of two return VOC_ERR_UNSUPPORTED here: their transforms go through a
+ * buffer that the library allocates.
  */
 #define VOC_STATIC_SCRATCH_BYTES (64u << 20)
 int32_t voc_roundtrip_static_dev(voc_ctx *ctx, const double *x, int64_t x_stride, int64_t length, int64_t channels,

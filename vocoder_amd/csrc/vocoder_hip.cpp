@@ -1508,6 +1508,28 @@ VOC_EXPORT int32_t voc_add_frames(voc_ctx *c, const double *mag1, const double *
 namespace {
 std::mutex g_free_mu;
 Staging g_free_staging;  // lives until the process ends
+int g_free_device = -1;  // the device g_free_staging's buffers belong to
+
+// Serialises the context-free entry points and keeps their staging on the calling thread's current
+// device (a thread that has switched devices gets a fresh staging there: device memory of one GPU is
+// not assumed to be reachable from another).
+struct FreeCall {
+    std::lock_guard<std::mutex> g;
+    FreeCall() : g(g_free_mu)
+    {
+        int dev = 0;
+        HIPCHK(hipGetDevice(&dev));
+        if (dev != g_free_device) {
+            if (g_free_device >= 0 && (g_free_staging.dev || g_free_staging.pin)) {
+                HIPCHK(hipSetDevice(g_free_device));
+                (void)hipDeviceSynchronize();
+                g_free_staging.release();
+                HIPCHK(hipSetDevice(dev));
+            }
+            g_free_device = dev;
+        }
+    }
+};
 
 voc::Params step_params(int hop, int n, long long k)
 {
@@ -1531,7 +1553,7 @@ VOC_EXPORT int32_t voc_analysis_step_hn(int32_t hop, int32_t n, int64_t K, const
     if (B * K > 0 && (!prev_ph || !spec || !ph_out || !mag || !ph_inc)) return VOC_ERR_INVALID;
     if (B * K == 0) return VOC_OK;
     return guarded(nullptr, [&]() -> int32_t {
-        std::lock_guard<std::mutex> g(g_free_mu);
+        FreeCall fc;
         const size_t cnt = (size_t)B * (size_t)K, nb = cnt * sizeof(double);
         HostCall h(g_free_staging, nullptr);
         const int dprev = h.add(nb), dspec = h.add(2 * nb), dph = h.add(nb), dmag = h.add(nb), dinc = h.add(nb);
@@ -1558,7 +1580,7 @@ VOC_EXPORT int32_t voc_synthesis_step_h(int32_t hop, int64_t K, const double *ph
     if (B * K > 0 && (!ph || !mag || !ph_inc || !ph_out || !spec)) return VOC_ERR_INVALID;
     if (B * K == 0) return VOC_OK;
     return guarded(nullptr, [&]() -> int32_t {
-        std::lock_guard<std::mutex> g(g_free_mu);
+        FreeCall fc;
         const size_t cnt = (size_t)B * (size_t)K, nb = cnt * sizeof(double);
         HostCall h(g_free_staging, nullptr);
         const int dph = h.add(nb), dmag = h.add(nb), dinc = h.add(nb), dout = h.add(nb), dspec = h.add(2 * nb);
@@ -1583,7 +1605,7 @@ VOC_EXPORT int32_t voc_frame_from_complex(const double *spec, double *mag, doubl
     if (count < 0 || (count > 0 && (!spec || !mag || !ph))) return VOC_ERR_INVALID;
     if (count == 0) return VOC_OK;
     return guarded(nullptr, [&]() -> int32_t {
-        std::lock_guard<std::mutex> g(g_free_mu);
+        FreeCall fc;
         const size_t nb = (size_t)count * sizeof(double);
         HostCall h(g_free_staging, nullptr);
         const int dspec = h.add(2 * nb), dmag = h.add(nb), dph = h.add(nb);
@@ -1605,7 +1627,7 @@ VOC_EXPORT int32_t voc_frame_to_complex(const double *mag, const double *ph, dou
     if (count < 0 || (count > 0 && (!spec || !mag || !ph))) return VOC_ERR_INVALID;
     if (count == 0) return VOC_OK;
     return guarded(nullptr, [&]() -> int32_t {
-        std::lock_guard<std::mutex> g(g_free_mu);
+        FreeCall fc;
         const size_t nb = (size_t)count * sizeof(double);
         HostCall h(g_free_staging, nullptr);
         const int dmag = h.add(nb), dph = h.add(nb), dspec = h.add(2 * nb);
@@ -1628,7 +1650,7 @@ VOC_EXPORT int32_t voc_add_frames_n(const double *mag1, const double *inc1, cons
     if (count < 0 || (count > 0 && (!mag1 || !inc1 || !mag2 || !inc2 || !mag_out || !inc_out))) return VOC_ERR_INVALID;
     if (count == 0) return VOC_OK;
     return guarded(nullptr, [&]() -> int32_t {
-        std::lock_guard<std::mutex> g(g_free_mu);
+        FreeCall fc;
         const size_t nb = (size_t)count * sizeof(double);
         HostCall h(g_free_staging, nullptr);
         const int a = h.add(nb), b = h.add(nb), d = h.add(nb), e = h.add(nb), mo = h.add(nb), io = h.add(nb);
@@ -1852,6 +1874,7 @@ VOC_EXPORT int32_t voc_roundtrip_static_dev(voc_ctx *c, const double *x, int64_t
     if (F > 0 && (!y || y_stride < ola_length(c, F, chunk))) return VOC_ERR_SIZE;
     if (leftover && leftover_stride < leftover_length(c, len)) return VOC_ERR_SIZE;
     if (!c->static_scratch) return VOC_ERR_HIP;
+    if (c->blue_big) return VOC_ERR_UNSUPPORTED;  // those transforms go through a buffer the library allocates
     // the channels run in groups that fit the array; one channel alone has to fit
     if (roundtrip_plan(c, len, 1, chunk).per_channel_bytes > kStaticScratchBytes) return VOC_ERR_SCRATCH;
     return guarded(c, [&]() -> int32_t {
