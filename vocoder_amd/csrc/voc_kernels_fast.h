@@ -24,6 +24,10 @@
 #define VOC_WS_PREFETCH 0  // fetch the window with the next frame's samples (aligned case)
 #endif
 
+#ifndef VOC_SYN_TW_LDS
+#define VOC_SYN_TW_LDS 0  // synthesis: twiddle rows of the passes at stride 8 and 64 read from LDS instead of formed by multiplication
+#endif
+
 #ifndef VOC_SYN_PHASE_REGS
 #define VOC_SYN_PHASE_REGS 1  // synthesis: accumulated phases in registers instead of LDS where the row prefetch is off
 #endif
@@ -232,6 +236,14 @@ VOC_DEV void twiddle8(C2 (&v)[8], C2 w1)
     v[7] = cmul(v[7], cmul(w4, w3));
 }
 
+// v[j] *= row[(j - 1) * stride], j = 1..7: the same factors read from a table ([j-1][k], k fastest)
+template <class C2>
+VOC_DEV void twiddle8_tab(C2 (&v)[8], const C2 *row, int stride)
+{
+#pragma unroll
+    for (int j = 1; j < 8; ++j) v[j] = cmul(v[j], row[(j - 1) * stride]);
+}
+
 // fourth pass: load, twiddle, butterfly (results stay in v); pass4_store writes them
 template <int LOG2M, class C2>
 VOC_DEV void pass4_compute(const C2 *lds, int tid, const FastTw<LOG2M, C2> &t, C2 (&v)[8])
@@ -287,21 +299,25 @@ VOC_DEV void pass4_store(C2 *lds, int tid, const C2 (&v)[8])
 // Passes 2..4 of the transform whose first-pass butterflies are already in v.  `prefetch` is
 // called once, after the last butterfly and before the last store: the place for the caller's
 // next-frame loads.
+// twl: optional table in LDS, the twiddle rows of the passes at stride 8 (56 entries) and 64 (448 entries).
 template <int LOG2M, class C2, class Prefetch>
-VOC_DEV void fft_after_first(C2 *lds, const FastTw<LOG2M, C2> &t, int tid, C2 (&v)[8], Prefetch prefetch)
+VOC_DEV void fft_after_first(C2 *lds, const FastTw<LOG2M, C2> &t, int tid, C2 (&v)[8], Prefetch prefetch,
+                             const C2 *twl = nullptr)
 {
     constexpr int R4 = FastCfg<LOG2M>::R4;
     __syncthreads();
     store8<LOG2M, 1>(lds, tid, v);
     __syncthreads();
     load8<LOG2M>(lds, tid, v);
-    twiddle8(v, t.b);
+    if (twl) twiddle8_tab(v, twl + (tid & 7), 8);
+    else twiddle8(v, t.b);
     dft<8>(v);
     __syncthreads();
     store8<LOG2M, 8>(lds, tid, v);
     __syncthreads();
     load8<LOG2M>(lds, tid, v);
-    twiddle8(v, t.c);
+    if (twl) twiddle8_tab(v, twl + 56 + (tid & 63), 64);
+    else twiddle8(v, t.c);
     dft<8>(v);
     if (R4 == 1) prefetch();
     __syncthreads();
@@ -546,6 +562,13 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
 
     FastTw<LOG2M, C2> tw;  // frame-invariant twiddle bases of this thread
     fast_tw_init<LOG2M>(p, tid, tw);
+    // with the phases in registers their LDS area is free: it can hold the twiddle rows of two passes
+    constexpr bool TW_LDS = VOC_SYN_TW_LDS && PHASE_REGS && LOG2M >= 10;
+    C2 *twl = reinterpret_cast<C2 *>(php);
+    if constexpr (TW_LDS) {
+        for (int i = tid; i < 56 + 448; i += T) twl[i] = i < 56 ? p.twP[7 + i] : p.twP[63 + (i - 56)];
+        __syncthreads();
+    }
     C2 tail[NT];  // overlap-add partial sums that later frames still add to
 #pragma unroll
     for (int j = 0; j < NT; ++j) tail[j] = mk2((R)0, (R)0);
@@ -640,7 +663,7 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
         dft<8>(v);
         fft_after_first<LOG2M>(lds, tw, lt, v, [&]() {
             if (ROW_PF && f + 1 < f1) load_row(f + 1, lt);
-        });
+        }, TW_LDS ? twl : nullptr);
         // lds[pad(m)] = swapped z[m]: v[2m] = z.y / N, v[2m+1] = z.x / N.  frame[i] = w[i] * v[(i + off + N/2) mod N]
         const bool emit = f >= f0;
         if (OLA) {
