@@ -56,8 +56,8 @@ enum {
 };
 
 /* VOC_PRECISION_F64: the reference's arithmetic; every entry point without `_f32` in its name.
- * VOC_PRECISION_F32: a reduced-precision variant of the fused path only (voc_roundtrip_f32*):
- * float samples, STFT and phases, the synthesis phase kept wrapped into [-pi, pi) (an
+ * VOC_PRECISION_F32: a reduced-precision variant (every entry point with `_f32` in its name: the fused
+ * round trip, the stage and signal levels, filter chains, streams): float samples, STFT and phases, the synthesis phase kept wrapped into [-pi, pi) (an
  * unwrapped float phase loses all resolution within a few thousand frames).  Its parity bar
  * is its own (tests/test_f32_cpu.py, tests/test_gpu_f32.py): relative L2 <= 2e-4 on output
  * samples against the double-precision oracle.  A context serves one precision; entry points
@@ -438,6 +438,46 @@ int32_t voc_stream_push_dev(voc_stream *s, const double *x, int64_t x_stride, in
                             int64_t y_cap, int64_t *n_out, void *stream);
 int32_t voc_stream_flush(voc_stream *s, double *y, int64_t y_stride, int64_t y_cap, int64_t *n_out);
 int32_t voc_stream_flush_dev(voc_stream *s, double *y, int64_t y_stride, int64_t y_cap, int64_t *n_out, void *stream);
+
+/* ---- single-precision forms (contexts created with VOC_PRECISION_F32) -------------------------------
+ * The stage-level and signal-level entry points on float data: the same arguments as their double
+ * forms, every array float.  They run the kernel templates of the fused single-precision round trip
+ * (float samples, STFT and phases; the synthesis phase kept wrapped), to that variant's own bar. */
+int32_t voc_analysis_stage_f32(voc_ctx *ctx, float *phase_io, const float *frames, float *mag, float *ph_inc,
+                               int64_t channels, int64_t nframes);
+int32_t voc_synthesis_stage_f32(voc_ctx *ctx, float *phase_io, const float *mag, const float *ph_inc, float *frames,
+                                int64_t channels, int64_t nframes);
+int32_t voc_analysis_stage_f32_dev(voc_ctx *ctx, float *phase_io, const float *frames, float *mag, float *ph_inc,
+                                   int64_t channels, int64_t nframes, void *stream);
+int32_t voc_synthesis_stage_f32_dev(voc_ctx *ctx, float *phase_io, const float *mag, const float *ph_inc, float *frames,
+                                    int64_t channels, int64_t nframes, void *stream);
+int32_t voc_analysis_signal_f32_dev(voc_ctx *ctx, const float *x, int64_t x_stride, int64_t nframes, int64_t channels,
+                                    float *phase_io, float *mag, float *ph_inc, int64_t ldk, int32_t volume_fix,
+                                    void *stream);
+int32_t voc_synthesis_signal_f32_dev(voc_ctx *ctx, const float *mag, const float *ph_inc, int64_t ldk, int64_t nframes,
+                                     int64_t channels, float *phase_io, float *y, int64_t y_stride, int64_t y_len,
+                                     void *stream);
+int32_t voc_synthesis_mapped_f32_dev(voc_ctx *ctx, const float *mag, int64_t mag_frames, const int64_t *mag_rows,
+                                     const float *ph_inc, int64_t inc_frames, const int64_t *inc_rows, int64_t ldk,
+                                     int64_t nframes, int64_t channels, float *phase_io, float *y, int64_t y_stride,
+                                     int64_t y_len, void *stream);
+/* A filter chain (voc_filter_create / voc_filter_append on the single-precision context) on a float STFT: the
+ * chain's arithmetic is the reference's, in double; rows are widened on load and rounded once on store.
+ * first_frame / first_channel as in voc_filter_apply_at_dev. */
+int32_t voc_filter_apply_f32_dev(voc_filter *f, float *mag, float *ph_inc, int64_t ldk, int64_t nframes, int64_t channels,
+                                 int64_t first_frame, int64_t first_channel, void *stream);
+int32_t voc_filter_apply_f32(voc_filter *f, float *mag, float *ph_inc, int64_t nframes, int64_t channels);
+/* A voc_stream created on a single-precision context holds float state; its data calls are these (the queries
+ * voc_stream_push_length / _flush_length, voc_stream_set_filter and voc_stream_set_play_speed serve both). */
+int32_t voc_stream_set_phases_f32(voc_stream *s, const float *ana_phase, const float *syn_phase);
+int32_t voc_stream_get_phases_f32(voc_stream *s, float *ana_phase, float *syn_phase);
+int64_t voc_stream_leftover_f32(voc_stream *s, float *out, int64_t out_stride);
+int32_t voc_stream_push_f32(voc_stream *s, const float *x, int64_t x_stride, int64_t n, float *y, int64_t y_stride,
+                            int64_t y_cap, int64_t *n_out);
+int32_t voc_stream_push_f32_dev(voc_stream *s, const float *x, int64_t x_stride, int64_t n, float *y, int64_t y_stride,
+                                int64_t y_cap, int64_t *n_out, void *stream);
+int32_t voc_stream_flush_f32(voc_stream *s, float *y, int64_t y_stride, int64_t y_cap, int64_t *n_out);
+int32_t voc_stream_flush_f32_dev(voc_stream *s, float *y, int64_t y_stride, int64_t y_cap, int64_t *n_out, void *stream);
 
 /* ---- measurement hook (no counterpart in the reference) ------------------------------------------
  * With profiling on, every kernel launch made through the context is bracketed by HIP events

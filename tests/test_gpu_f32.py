@@ -39,3 +39,55 @@ def test_f32_roundtrip_on_device(gpu_lib, orc, n, w, hop):
     err = np.linalg.norm(y_host[0] - ref["y"]) / np.linalg.norm(ref["y"])
     assert err <= TOL_F32_L2, err
     assert np.abs(sph).max() <= np.pi + 1e-6
+
+
+@pytest.mark.parametrize("n,w,hop", [(4096, 4096, 1024), (2048, 1500, 512), (256, 256, 64)])
+def test_f32_stage_signal_filter_and_stream_forms_on_device(gpu_lib, orc, n, w, hop):
+    """The single-precision forms beyond the fused call: stages against the double-precision oracle to the variant's
+    bar; the two halves of the fused call, and a stream pushed in pieces, equal to the fused call bit for bit; a filter
+    chain on the float STFT equal to the double chain on the widened rows, rounded once."""
+    import torch
+    from vocoder_amd import vocoder as V, conduit as Cd, stream as S, filter as Fl
+    win = _hann(w)
+    p32 = V.VocoderParams(n, hop, win, lib=gpu_lib, precision="f32")
+    p64 = V.VocoderParams(n, hop, win, lib=gpu_lib)
+    rng = np.random.default_rng(n + 3)
+    c, f = 2, 12
+    length = w + hop * (f - 1)
+    t = np.arange(length)
+    x = np.stack([0.5 * np.sin(2 * np.pi * 0.0093 * (i + 1) * t + i) for i in range(c)]) + 0.01 * rng.uniform(-1, 1, (c, length))
+    x32 = x.astype(np.float32)
+    frames = np.stack([[x32[ch, j * hop:j * hop + w] for j in range(f)] for ch in range(c)])
+    aph, (mag, inc) = V.analysis_stage(p32, np.zeros((c, p32.K), dtype=np.float32), frames)
+    sph, out = V.synthesis_stage(p32, np.zeros((c, p32.K), dtype=np.float32), (mag, inc))
+    assert mag.dtype == np.float32 and out.dtype == np.float32
+    for ch in range(c):
+        _, rmag, rinc = orc.analysis_stage(n, hop, win, np.zeros(p32.K), frames[ch].astype(np.float64))
+        assert np.linalg.norm(mag[ch] - rmag) <= 1e-5 * np.linalg.norm(rmag)
+        _, rframes = orc.synthesis_stage(n, hop, win, np.zeros(p32.K), rmag, rinc)
+        assert np.linalg.norm(out[ch] - rframes) <= TOL_F32_L2 * np.linalg.norm(rframes)
+    xt = torch.from_numpy(x32).cuda()
+    y_ref, left_ref, (a_ref, s_ref) = Cd.process_with(p32, x32)
+    y, a2, s2 = Cd.process_filter_dev(p32, None, xt)
+    torch.cuda.synchronize()
+    assert np.array_equal(y.cpu().numpy(), y_ref) and np.array_equal(s2.cpu().numpy(), s_ref)
+    st = S.Stream(p32, c)
+    outs = [st.push(x32[:, :length // 3]), st.push_dev(xt[:, length // 3:length // 2].contiguous()).cpu().numpy(),
+            st.push(x32[:, length // 2:]), st.flush()]
+    assert np.array_equal(np.concatenate(outs, axis=1), y_ref)
+    a, sp = st.phases()
+    assert np.array_equal(a, a_ref) and np.array_equal(sp, s_ref) and np.array_equal(st.leftover(), left_ref)
+    desc = Fl.pitch_shift_interpolate(1.5) >> Fl.lowpass_butterworth(2.0, 5000.0) >> Fl.amplify(0.7)
+    m32, i32 = desc.bind(p32, 48000.0 / n).apply(mag, inc)
+    m64, i64 = desc.bind(p64, 48000.0 / n).apply(mag.astype(np.float64), inc.astype(np.float64))
+    assert np.array_equal(m32, m64.astype(np.float32)) and np.array_equal(i32, i64.astype(np.float32))
+    filt = (Fl.lowpass_brickwall(6000.0) >> Fl.play_speed(2)).bind(p32, 48000.0 / n)
+    yf_ref = Cd.process_filter_dev(p32, filt, xt)[0].cpu().numpy()
+    sf = S.Stream(p32, c, filt=filt)
+    yf = np.concatenate([sf.push(x32[:, :length // 2]), sf.push(x32[:, length // 2:]), sf.flush()], axis=1)
+    # (a single-precision batch reads replicated rows through maps with the general kernels, the stream copies
+    #  them and may take the specialised ones: two transforms, the same values to float rounding)
+    assert yf.shape == yf_ref.shape and np.linalg.norm(yf - yf_ref) <= 1e-5 * np.linalg.norm(yf_ref)
+    ref = Cd.process_filter_dev(p64, (Fl.lowpass_brickwall(6000.0) >> Fl.play_speed(2)).bind(p64, 48000.0 / n),
+                                torch.from_numpy(x32.astype(np.float64)).cuda())[0].cpu().numpy()
+    assert np.linalg.norm(yf - ref) <= TOL_F32_L2 * np.linalg.norm(ref)

@@ -53,6 +53,15 @@ SIGNATURES = {
     "voc_roundtrip_workspace_bytes": (_i64, [_vp, _i64, _i64]),
     "voc_analysis_signal_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
     "voc_synthesis_signal_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _vp]),
+    "voc_filter_apply_f32_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp]),
+    "voc_filter_apply_f32": (_i32, [_vp, _vp, _vp, _i64, _i64]),
+    "voc_synthesis_mapped_f32_dev": (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _vp]),
+    "voc_analysis_signal_f32_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "voc_synthesis_signal_f32_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _vp]),
+    "voc_analysis_stage_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64]),
+    "voc_synthesis_stage_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64]),
+    "voc_analysis_stage_f32_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "voc_synthesis_stage_f32_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "voc_phase_advance_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "voc_filter_create": (_i32, [_vp, C.c_double, C.POINTER(_vp)]),
     "voc_filter_destroy": (_i32, [_vp]),
@@ -76,6 +85,13 @@ SIGNATURES = {
     "voc_stream_create_mode": (_i32, [_vp, _i64, _i64, _vp, _i32, C.POINTER(_vp)]),
     "voc_stream_set_filter": (_i32, [_vp, _vp]),
     "voc_stream_set_play_speed": (_i32, [_vp, _i64, _i64, _vp]),
+    "voc_stream_set_phases_f32": (_i32, [_vp, _vp, _vp]),
+    "voc_stream_get_phases_f32": (_i32, [_vp, _vp, _vp]),
+    "voc_stream_leftover_f32": (_i64, [_vp, _vp, _i64]),
+    "voc_stream_push_f32": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, C.POINTER(_i64)]),
+    "voc_stream_push_f32_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, C.POINTER(_i64), _vp]),
+    "voc_stream_flush_f32": (_i32, [_vp, _vp, _i64, _i64, C.POINTER(_i64)]),
+    "voc_stream_flush_f32_dev": (_i32, [_vp, _vp, _i64, _i64, C.POINTER(_i64), _vp]),
     "voc_stream_destroy": (_i32, [_vp]),
     "voc_stream_set_phases": (_i32, [_vp, _vp, _vp]),
     "voc_stream_get_phases": (_i32, [_vp, _vp, _vp]),

@@ -163,37 +163,40 @@ def process_filter_dev(par: VocoderParams, filt, x, length: int | None = None, c
     volumeFix .| filter .| synthesis .| overlap-add, all in device memory.
 
     filt: a `vocoder_amd.filter.BoundFilter` (or None for idFilter).  x (C, >= length) is a torch
-    float64 tensor on the GPU (or in host memory with the host build of the kernels used by the
+    float64 tensor (float32 on a single-precision context) on the GPU (or in host memory with the host build of the kernels used by the
     CPU tests); phases (C, K) are updated in place when given.  Returns (y, ana_phase, syn_phase)
     with y (C, ola_length(frames after the filter))."""
     import torch
 
-    assert x.dtype == torch.float64 and x.stride(-1) == 1
+    f32 = getattr(par, "precision", "f64") == "f32"
+    dt = torch.float32 if f32 else torch.float64
+    sfx = "_f32_dev" if f32 else "_dev"
+    assert x.dtype == dt and x.stride(-1) == 1
     c = x.shape[0]
     length = x.shape[1] if length is None else length
     chunk = par.H if chunk is None else chunk
     dev = x.device
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if x.is_cuda else None
-    aph = torch.zeros((c, par.K), dtype=torch.float64, device=dev) if ana_phase is None else ana_phase
-    sph = torch.zeros((c, par.K), dtype=torch.float64, device=dev) if syn_phase is None else syn_phase
+    aph = torch.zeros((c, par.K), dtype=dt, device=dev) if ana_phase is None else ana_phase
+    sph = torch.zeros((c, par.K), dtype=dt, device=dev) if syn_phase is None else syn_phase
     f = num_frames(par, length)
     ldk = (par.K + 1) & ~1
-    mag = torch.empty((c, f, ldk), dtype=torch.float64, device=dev)
+    mag = torch.empty((c, f, ldk), dtype=dt, device=dev)
     inc = torch.empty_like(mag)
     if f:
-        par._call("voc_analysis_signal_dev", C.c_void_p(x.data_ptr()), x.stride(0), f, c, C.c_void_p(aph.data_ptr()),
+        par._call("voc_analysis_signal" + sfx, C.c_void_p(x.data_ptr()), x.stride(0), f, c, C.c_void_p(aph.data_ptr()),
                   C.c_void_p(mag.data_ptr()), C.c_void_p(inc.data_ptr()), ldk, 1, st)
     mrows = irows = None
     fo = f
     if filt is not None:
         mag, mrows, inc, irows, fo = filt.apply_dev_lazy(mag, inc)
     n = ola_length(par, fo, chunk)
-    y = torch.empty((c, n), dtype=torch.float64, device=dev)
+    y = torch.empty((c, n), dtype=dt, device=dev)
     if fo and mrows is None and irows is None:
-        par._call("voc_synthesis_signal_dev", C.c_void_p(mag.data_ptr()), C.c_void_p(inc.data_ptr()), ldk, fo, c,
+        par._call("voc_synthesis_signal" + sfx, C.c_void_p(mag.data_ptr()), C.c_void_p(inc.data_ptr()), ldk, fo, c,
                   C.c_void_p(sph.data_ptr()), C.c_void_p(y.data_ptr()), y.stride(0), n, st)
     elif fo:   # play_speed: synthesis reads the rows through the maps, nothing is copied
-        par._call("voc_synthesis_mapped_dev", C.c_void_p(mag.data_ptr()), mag.shape[1],
+        par._call("voc_synthesis_mapped" + sfx, C.c_void_p(mag.data_ptr()), mag.shape[1],
                   C.c_void_p(mrows.data_ptr()) if mrows is not None else None,
                   C.c_void_p(inc.data_ptr()), inc.shape[1], C.c_void_p(irows.data_ptr()) if irows is not None else None,
                   ldk, fo, c, C.c_void_p(sph.data_ptr()), C.c_void_p(y.data_ptr()), y.stride(0), n, st)

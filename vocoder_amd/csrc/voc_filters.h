@@ -104,10 +104,12 @@ struct FiltCfg {
 // One workgroup per STFT row at a time.  The row lives in registers (thread t holds bins t + T*j);
 // operations that read neighbouring bins stage it through LDS (2 * (K+1) doubles, only allocated
 // when the chain holds such an operation).
-template <int LOG2M>
+// S: the type the STFT is stored in.  The arithmetic is the reference's, in double, whatever S is: a float
+// STFT (single-precision contexts) is widened on load and rounded once on store.
+template <int LOG2M, class S = double>
 __global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p, FilterProg prog,
-                                                                        double *__restrict__ mag,
-                                                                        double *__restrict__ inc, long long ldk,
+                                                                        S *__restrict__ mag,
+                                                                        S *__restrict__ inc, long long ldk,
                                                                         long long rows, long long F, long long rpc,
                                                                         long long first_frame, long long first_channel)
 {
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p
     for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
         // row = channel * F + frame; the arrays hold rpc >= F rows per channel
         const long long prow = rpc == F ? row : (row / F) * rpc + row % F;
-        double *mrow = mag + prow * ldk, *irow = inc + prow * ldk;
+        S *mrow = mag + prow * ldk, *irow = inc + prow * ldk;
         double m[NE], ic[NE];
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
@@ -129,8 +131,8 @@ __global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p
             m[j] = 0.0;
             ic[j] = 0.0;
             if (k < K) {
-                if (prog.load_mag) m[j] = mrow[k];
-                if (prog.load_inc) ic[j] = irow[k];
+                if (prog.load_mag) m[j] = (double)mrow[k];
+                if (prog.load_inc) ic[j] = (double)irow[k];
             }
         }
         for (int o = 0; o < prog.n; ++o) {
@@ -214,17 +216,18 @@ __global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p
         for (int j = 0; j < NE; ++j) {
             const int k = tid + T * j;
             if (k < K) {
-                if (prog.store_mag) mrow[k] = m[j];
-                if (prog.store_inc) irow[k] = ic[j];
+                if (prog.store_mag) mrow[k] = (S)m[j];
+                if (prog.store_inc) irow[k] = (S)ic[j];
             }
         }
     }
 }
 
 // playSpeed: output frame j of every channel is input frame src[j] (Conduit/Filter.hs:122-136).
-__global__ void gather_frames_kernel(const double *__restrict__ mag_in, const double *__restrict__ inc_in, long long ldk,
+template <class S = double>
+__global__ void gather_frames_kernel(const S *__restrict__ mag_in, const S *__restrict__ inc_in, long long ldk,
                                      long long F_in, const long long *__restrict__ src, long long F_out,
-                                     double *__restrict__ mag_out, double *__restrict__ inc_out, long long total)
+                                     S *__restrict__ mag_out, S *__restrict__ inc_out, long long total)
 {
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
         const long long k = g % ldk;
@@ -240,10 +243,11 @@ __global__ void gather_frames_kernel(const double *__restrict__ mag_in, const do
 // floor((i+1) num / den) - floor(i num / den) times, so output frame t of the stream is input frame
 // floor(((t+1) den - 1) / num).  Output rows out_first .. out_first + G of every channel are copied from
 // the input rows held from in_first on; rows of a channel are in_rpc / out_rpc rows apart.
-__global__ void replicate_frames_kernel(const double *__restrict__ mag_in, const double *__restrict__ inc_in,
+template <class S = double>
+__global__ void replicate_frames_kernel(const S *__restrict__ mag_in, const S *__restrict__ inc_in,
                                         long long in_rpc, long long in_first, long long ldk, long long num, long long den,
-                                        long long out_first, long long G, double *__restrict__ mag_out,
-                                        double *__restrict__ inc_out, long long out_rpc, long long total)
+                                        long long out_first, long long G, S *__restrict__ mag_out,
+                                        S *__restrict__ inc_out, long long out_rpc, long long total)
 {
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
         const long long k = g % ldk;

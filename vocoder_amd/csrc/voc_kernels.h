@@ -1016,29 +1016,31 @@ __global__ void phase_carry_kernel(ParamsT<R> p, const R *__restrict__ inc, long
 // The synthesis phase chain alone: phase_io <- fold (ph + ph_inc * H) over the F frames, in frame
 // order (synthesisStep, Vocoder.hs:190).  Used where only the phase a run of frames ends on is
 // needed (time-sharded runs exchange it between segments).
-__global__ void phase_advance_kernel(Params p, const double *__restrict__ inc, long long ldk, long long F,
-                                     double *__restrict__ phase_io, long long channels, long long rpc)
+template <class R = double>
+__global__ void phase_advance_kernel(ParamsT<R> p, const R *__restrict__ inc, long long ldk, long long F,
+                                     R *__restrict__ phase_io, long long channels, long long rpc)
 {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= channels * p.K) return;
     const long long c = g / p.K;
     const int k = (int)(g % p.K);
-    double ph = phase_io[g];
-    const double *src = inc + c * rpc * ldk + k;  // rpc rows per channel, the first F of them folded
+    R ph = phase_io[g];
+    const R *src = inc + c * rpc * ldk + k;  // rpc rows per channel, the first F of them folded
     long long f = 0;
     for (; f + 16 <= F; f += 16) {
-        double dd[16];
+        R dd[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) dd[u] = src[(f + u) * ldk];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) ph = ph + dd[u] * p.hop_d;
+        for (int u = 0; u < 16; ++u) ph = phase_step(ph, dd[u] * p.hop_d);
     }
-    for (; f < F; ++f) ph = ph + src[f * ldk] * p.hop_d;
+    for (; f < F; ++f) ph = phase_step(ph, src[f * ldk] * p.hop_d);
     phase_io[g] = ph;
 }
 
-// rows[r][0 .. width) *= factor, rows `pitch` doubles apart (volumeFix on samples, Dunai.hs:41-42)
-__global__ void scale_rows_kernel(double *__restrict__ rows, long long pitch, long long width, long long total, double factor)
+// rows[r][0 .. width) *= factor, rows `pitch` elements apart (volumeFix on samples, Dunai.hs:41-42)
+template <class R = double>
+__global__ void scale_rows_kernel(R *__restrict__ rows, long long pitch, long long width, long long total, R factor)
 {
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
         const long long r = g / width, i = g % width;

@@ -746,16 +746,17 @@ inline long long leftover_length(const voc_ctx *c, long long len)
 
 // ---- device-pointer bodies (ctx->mu held, device set) -------------------------------------------
 
-void analysis_stage_dev(voc_ctx *c, double *phase_io, const double *frames, double *mag, double *inc, long long C,
+template <class R = double>
+void analysis_stage_dev(voc_ctx *c, R *phase_io, const R *frames, R *mag, R *inc, long long C,
                         long long F, hipStream_t st)
 {
     if (C <= 0 || F <= 0) return;
     WsUse use(c, st);
     // the kernel reads the initial phases while another tile may already write the final ones
-    ensure_ws(c, (size_t)C * c->K * sizeof(double));
-    double *pin = static_cast<double *>(c->ws);
-    HIPCHK(hipMemcpyAsync(pin, phase_io, (size_t)C * c->K * sizeof(double), hipMemcpyDeviceToDevice, st));
-    voc::AnaArgs a{};
+    ensure_ws(c, (size_t)C * c->K * sizeof(R));
+    R *pin = static_cast<R *>(c->ws);
+    HIPCHK(hipMemcpyAsync(pin, phase_io, (size_t)C * c->K * sizeof(R), hipMemcpyDeviceToDevice, st));
+    voc::AnaArgsT<R> a{};
     a.x = frames;
     a.chan_stride = F * c->W;
     a.frame_stride = c->W;
@@ -768,32 +769,33 @@ void analysis_stage_dev(voc_ctx *c, double *phase_io, const double *frames, doub
     a.rpc = F;
     a.tile_len = analysis_tile_len(c, C, F);
     a.tiles = (int)((F + a.tile_len - 1) / a.tile_len);
-    a.vol = 1.0;
-    if (!launch_analysis_fast(c, a, C, st)) launch_analysis<false, false>(c, a, C, st);
+    a.vol = (R)1;
+    if (!launch_analysis_fast<R>(c, a, C, st)) launch_analysis<false, false, R>(c, a, C, st);
 }
 
-void synthesis_stage_dev(voc_ctx *c, double *phase_io, const double *mag, const double *inc, double *frames,
+template <class R = double>
+void synthesis_stage_dev(voc_ctx *c, R *phase_io, const R *mag, const R *inc, R *frames,
                          long long C, long long F, hipStream_t st)
 {
     if (C <= 0 || F <= 0) return;
     WsUse use(c, st);
     int tile_len, tiles;
     synthesis_tiling(c, C, F, 0, &tile_len, &tiles);
-    const size_t pin_bytes = (size_t)C * c->K * sizeof(double);
-    const size_t carry_bytes = tiles > 1 ? (size_t)C * tiles * c->K * sizeof(double) : 0;
+    const size_t pin_bytes = (size_t)C * c->K * sizeof(R);
+    const size_t carry_bytes = tiles > 1 ? (size_t)C * tiles * c->K * sizeof(R) : 0;
     ensure_ws(c, pin_bytes + carry_bytes);
-    double *pin = static_cast<double *>(c->ws);
-    double *carry = pin + (size_t)C * c->K;
+    R *pin = static_cast<R *>(c->ws);
+    R *carry = pin + (size_t)C * c->K;
     HIPCHK(hipMemcpyAsync(pin, phase_io, pin_bytes, hipMemcpyDeviceToDevice, st));
     if (tiles > 1) {
         const long long chains = C * c->K;
         LaunchTimer timer(c, KIND_CARRY, st);
-        hipLaunchKernelGGL(voc::phase_carry_kernel<double>, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st,
-                           c->params, inc, (long long)c->K, F, pin, carry, tile_len, tiles, 0, C,
+        hipLaunchKernelGGL(voc::phase_carry_kernel<R>, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st,
+                           params_of<R>(c), inc, (long long)c->K, F, (const R *)pin, carry, tile_len, tiles, 0, C,
                            (const long long *)nullptr, 0LL);
         HIPCHK(hipGetLastError());
     }
-    voc::SynArgs a{};
+    voc::SynArgsT<R> a{};
     a.mag = mag;
     a.inc = inc;
     a.ldk = c->K;
@@ -805,21 +807,22 @@ void synthesis_stage_dev(voc_ctx *c, double *phase_io, const double *mag, const 
     a.tile_len = tile_len;
     a.tiles = tiles;
     a.halo = 0;
-    if (!launch_synthesis_fast(c, a, C, false, st)) launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_FRAMES>(c, a, C, st);
+    if (!launch_synthesis_fast<R>(c, a, C, false, st)) launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_FRAMES, R>(c, a, C, st);
 }
 
 // genFramesOfE + analysisStage (+ volumeFix) on signal rows: frame j of a channel is read in place
 // at sample j*H (Frames.hs:34-35).
 // rpc: rows per channel of mag / inc (0: F); with more, mag / inc point at the row frame 0 goes to
-void analysis_signal_dev(voc_ctx *c, const double *x, long long x_stride, long long F, long long C, double *phase_io,
-                         double *mag, double *inc, long long ldk, bool volume_fix, hipStream_t st, long long rpc = 0)
+template <class R = double>
+void analysis_signal_dev(voc_ctx *c, const R *x, long long x_stride, long long F, long long C, R *phase_io,
+                         R *mag, R *inc, long long ldk, bool volume_fix, hipStream_t st, long long rpc = 0)
 {
     if (C <= 0 || F <= 0) return;
     WsUse use(c, st);
-    ensure_ws(c, (size_t)C * c->K * sizeof(double));
-    double *pin = static_cast<double *>(c->ws);
-    HIPCHK(hipMemcpyAsync(pin, phase_io, (size_t)C * c->K * sizeof(double), hipMemcpyDeviceToDevice, st));
-    voc::AnaArgs a{};
+    ensure_ws(c, (size_t)C * c->K * sizeof(R));
+    R *pin = static_cast<R *>(c->ws);
+    HIPCHK(hipMemcpyAsync(pin, phase_io, (size_t)C * c->K * sizeof(R), hipMemcpyDeviceToDevice, st));
+    voc::AnaArgsT<R> a{};
     a.x = x;
     a.chan_stride = x_stride;
     a.frame_stride = c->H;
@@ -832,8 +835,8 @@ void analysis_signal_dev(voc_ctx *c, const double *x, long long x_stride, long l
     a.rpc = rpc ? rpc : F;
     a.tile_len = analysis_tile_len(c, C, F);
     a.tiles = (int)((F + a.tile_len - 1) / a.tile_len);
-    a.vol = volume_fix ? c->vol : 1.0;
-    if (!launch_analysis_fast(c, a, C, st)) launch_analysis<false, false>(c, a, C, st);
+    a.vol = volume_fix ? (R)c->vol : (R)1;
+    if (!launch_analysis_fast<R>(c, a, C, st)) launch_analysis<false, false, R>(c, a, C, st);
 }
 
 constexpr size_t kLdsLimit = 160 * 1024;
@@ -841,14 +844,15 @@ constexpr size_t kLdsLimit = 160 * 1024;
 // synthesisStage + sumFramesE: y rows receive y_len samples each (zeros past the last frame).
 long long synthesis_unsplit(const voc_ctx *c, long long channels, long long F, int halo, bool fused, int *tile_len, int *tiles);
 
-void synthesis_signal_dev(voc_ctx *c, const double *mag, const double *inc, long long ldk, long long F, long long C,
-                          double *phase_io, double *y, long long y_stride, long long y_len, hipStream_t st,
+template <class R = double>
+void synthesis_signal_dev(voc_ctx *c, const R *mag, const R *inc, long long ldk, long long F, long long C,
+                          R *phase_io, R *y, long long y_stride, long long y_len, hipStream_t st,
                           const long long *mag_rows = nullptr, long long F_mag = 0, const long long *inc_rows = nullptr,
                           long long F_inc = 0)
 {
     if (C <= 0 || F <= 0) return;
     WsUse use(c, st);
-    const bool fused = !c->bluestein && lds_bytes(c, true) <= kLdsLimit;
+    const bool fused = !c->bluestein && lds_bytes<R>(c, true) <= kLdsLimit;
     const int halo = fused ? (c->W + c->H - 1) / c->H - 1 : 0;
     int tile_len, tiles;
     synthesis_tiling(c, C, F, halo, &tile_len, &tiles);
@@ -856,20 +860,20 @@ void synthesis_signal_dev(voc_ctx *c, const double *mag, const double *inc, long
     const size_t nph = (size_t)C * c->K;
     const size_t ncarry = tiles > 1 ? (size_t)C * tiles * c->K : 0;
     const size_t nframes = fused ? 0 : (size_t)C * F * c->W;
-    ensure_ws(c, (nph + ncarry + nframes) * sizeof(double));
-    double *pin = static_cast<double *>(c->ws);
-    double *carry = pin + nph;
-    double *frames = carry + ncarry;
-    HIPCHK(hipMemcpyAsync(pin, phase_io, nph * sizeof(double), hipMemcpyDeviceToDevice, st));
+    ensure_ws(c, (nph + ncarry + nframes) * sizeof(R));
+    R *pin = static_cast<R *>(c->ws);
+    R *carry = pin + nph;
+    R *frames = carry + ncarry;
+    HIPCHK(hipMemcpyAsync(pin, phase_io, nph * sizeof(R), hipMemcpyDeviceToDevice, st));
     if (tiles > 1 && C > unsplit) {
         const long long chains = (C - unsplit) * c->K;
         LaunchTimer timer(c, KIND_CARRY, st);
-        hipLaunchKernelGGL(voc::phase_carry_kernel<double>, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, c->params,
-                           inc + (size_t)unsplit * (F_inc ? F_inc : F) * ldk, ldk, F, (const double *)(pin + unsplit * c->K), carry,
+        hipLaunchKernelGGL(voc::phase_carry_kernel<R>, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, params_of<R>(c),
+                           inc + (size_t)unsplit * (F_inc ? F_inc : F) * ldk, ldk, F, (const R *)(pin + unsplit * c->K), carry,
                            tile_len, tiles, halo, C - unsplit, inc_rows, F_inc);
         HIPCHK(hipGetLastError());
     }
-    voc::SynArgs s{};
+    voc::SynArgsT<R> s{};
     s.mag = mag;
     s.inc = inc;
     s.ldk = ldk;
@@ -889,24 +893,25 @@ void synthesis_signal_dev(voc_ctx *c, const double *mag, const double *inc, long
     s.F_mag = F_mag;
     s.F_inc = F_inc;
     if (fused) {
-        if (!launch_synthesis_fast(c, s, C, true, st)) launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_OLA>(c, s, C, st);
+        if (!launch_synthesis_fast<R>(c, s, C, true, st)) launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_OLA, R>(c, s, C, st);
     } else {
         s.out = frames;
-        if (!launch_synthesis_fast(c, s, C, false, st)) launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_FRAMES>(c, s, C, st);
+        if (!launch_synthesis_fast<R>(c, s, C, false, st)) launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_FRAMES, R>(c, s, C, st);
         const long long total = C * y_len;
-        hipLaunchKernelGGL(voc::sum_frames_kernel<double>, dim3(ew_grid(total)), dim3(256), 0, st, frames, F, c->W, c->H, y,
+        hipLaunchKernelGGL(voc::sum_frames_kernel<R>, dim3(ew_grid(total)), dim3(256), 0, st, (const R *)frames, F, c->W, c->H, y,
                            y_stride, y_len, total);
         HIPCHK(hipGetLastError());
     }
 }
 
-void phase_advance_dev(voc_ctx *c, const double *inc, long long ldk, long long F, long long C, double *phase_io,
+template <class R = double>
+void phase_advance_dev(voc_ctx *c, const R *inc, long long ldk, long long F, long long C, R *phase_io,
                        hipStream_t st, long long rpc = 0)
 {
     if (C <= 0 || F <= 0) return;
     const long long chains = C * c->K;
     LaunchTimer timer(c, KIND_CARRY, st);
-    hipLaunchKernelGGL(voc::phase_advance_kernel, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, c->params, inc,
+    hipLaunchKernelGGL(voc::phase_advance_kernel<R>, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, params_of<R>(c), inc,
                        ldk, F, phase_io, C, rpc ? rpc : F);
     HIPCHK(hipGetLastError());
 }
@@ -918,7 +923,7 @@ long long synthesis_slots(const voc_ctx *c)
     if (c->syn_slots_override > 0) return c->syn_slots_override;  // VOC_SYN_SLOTS: lets small tests reach this path
     const bool f32 = c->precision == VOC_PRECISION_F32;
     const long long t = c->M / 8;
-    const long long lds = (long long)((c->M + (c->M >> 3) + 2) * 2 + ((c->K + 1) & ~1)) * (f32 ? 4 : 8);
+    const long long lds = (long long)(c->M * 2 + ((c->K + 1) & ~1)) * (f32 ? 4 : 8);  // FastCfg::lds_bytes
     long long by_lds = (long long)kLdsLimit / lds, by_regs = (f32 ? 16 : 12) * 64 / t;
     long long per_cu = by_lds < by_regs ? by_lds : by_regs;
     if (per_cu < 1) per_cu = 1;
@@ -2048,6 +2053,132 @@ VOC_EXPORT int32_t voc_roundtrip_f32(voc_ctx *c, const float *x, int64_t x_strid
 }
 
 // ---- measurement hook -----------------------------------------------------------------------------------------
+
+// ---- single-precision forms of the stage-level and signal-level entry points ---------------------------
+// (the same kernel templates on float; contexts made with VOC_PRECISION_F32)
+
+VOC_EXPORT int32_t voc_analysis_stage_f32_dev(voc_ctx *c, float *phase_io, const float *frames, float *mag, float *ph_inc,
+                                              int64_t C, int64_t F, void *stream)
+{
+    if (!c || C < 0 || F < 0) return VOC_ERR_INVALID;
+    if (C > 0 && F > 0 && (!phase_io || !frames || !mag || !ph_inc)) return VOC_ERR_INVALID;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c, VOC_PRECISION_F32);
+        analysis_stage_dev<float>(c, phase_io, frames, mag, ph_inc, C, F, (hipStream_t)stream);
+        return VOC_OK;
+    });
+}
+
+VOC_EXPORT int32_t voc_synthesis_stage_f32_dev(voc_ctx *c, float *phase_io, const float *mag, const float *ph_inc,
+                                               float *frames, int64_t C, int64_t F, void *stream)
+{
+    if (!c || C < 0 || F < 0) return VOC_ERR_INVALID;
+    if (C > 0 && F > 0 && (!phase_io || !frames || !mag || !ph_inc)) return VOC_ERR_INVALID;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c, VOC_PRECISION_F32);
+        synthesis_stage_dev<float>(c, phase_io, mag, ph_inc, frames, C, F, (hipStream_t)stream);
+        return VOC_OK;
+    });
+}
+
+VOC_EXPORT int32_t voc_analysis_stage_f32(voc_ctx *c, float *phase_io, const float *frames, float *mag, float *ph_inc,
+                                          int64_t C, int64_t F)
+{
+    if (!c || C < 0 || F < 0) return VOC_ERR_INVALID;
+    if (C == 0 || F == 0) return VOC_OK;
+    if (!phase_io || !frames || !mag || !ph_inc) return VOC_ERR_INVALID;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c, VOC_PRECISION_F32);
+        const size_t nph = (size_t)C * c->K * sizeof(float), nfr = (size_t)C * F * c->W * sizeof(float),
+                     nst = (size_t)C * F * c->K * sizeof(float);
+        HostCall h(c->staging, nullptr);
+        const int dfr = h.add(nfr), dph = h.add(nph), dmag = h.add(nst), dinc = h.add(nst);
+        h.commit();
+        h.upload(dfr, frames);
+        h.upload(dph, phase_io);
+        h.uploads_done();
+        analysis_stage_dev<float>(c, h.dev<float>(dph), h.dev<float>(dfr), h.dev<float>(dmag), h.dev<float>(dinc), C, F, nullptr);
+        h.download(dph, phase_io);
+        h.download(dmag, mag);
+        h.download(dinc, ph_inc);
+        h.finish();
+        return VOC_OK;
+    });
+}
+
+VOC_EXPORT int32_t voc_synthesis_stage_f32(voc_ctx *c, float *phase_io, const float *mag, const float *ph_inc, float *frames,
+                                           int64_t C, int64_t F)
+{
+    if (!c || C < 0 || F < 0) return VOC_ERR_INVALID;
+    if (C == 0 || F == 0) return VOC_OK;
+    if (!phase_io || !frames || !mag || !ph_inc) return VOC_ERR_INVALID;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c, VOC_PRECISION_F32);
+        const size_t nph = (size_t)C * c->K * sizeof(float), nfr = (size_t)C * F * c->W * sizeof(float),
+                     nst = (size_t)C * F * c->K * sizeof(float);
+        HostCall h(c->staging, nullptr);
+        const int dmag = h.add(nst), dinc = h.add(nst), dph = h.add(nph), dfr = h.add(nfr);
+        h.commit();
+        h.upload(dmag, mag);
+        h.upload(dinc, ph_inc);
+        h.upload(dph, phase_io);
+        h.uploads_done();
+        synthesis_stage_dev<float>(c, h.dev<float>(dph), h.dev<float>(dmag), h.dev<float>(dinc), h.dev<float>(dfr), C, F, nullptr);
+        h.download(dph, phase_io);
+        h.download(dfr, frames);
+        h.finish();
+        return VOC_OK;
+    });
+}
+
+VOC_EXPORT int32_t voc_analysis_signal_f32_dev(voc_ctx *c, const float *x, int64_t x_stride, int64_t F, int64_t C,
+                                               float *phase_io, float *mag, float *ph_inc, int64_t ldk, int32_t volume_fix,
+                                               void *stream)
+{
+    if (!c || C < 0 || F < 0) return VOC_ERR_INVALID;
+    if (C == 0 || F == 0) return VOC_OK;
+    if (!x || !phase_io || !mag || !ph_inc) return VOC_ERR_INVALID;
+    if (ldk < c->K || x_stride < (F - 1) * (int64_t)c->H + c->W) return VOC_ERR_SIZE;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c, VOC_PRECISION_F32);
+        analysis_signal_dev<float>(c, x, x_stride, F, C, phase_io, mag, ph_inc, ldk, volume_fix != 0, (hipStream_t)stream);
+        return VOC_OK;
+    });
+}
+
+VOC_EXPORT int32_t voc_synthesis_signal_f32_dev(voc_ctx *c, const float *mag, const float *ph_inc, int64_t ldk, int64_t F,
+                                                int64_t C, float *phase_io, float *y, int64_t y_stride, int64_t y_len,
+                                                void *stream)
+{
+    if (!c || C < 0 || F < 0) return VOC_ERR_INVALID;
+    if (C == 0 || F == 0) return VOC_OK;
+    if (!mag || !ph_inc || !phase_io || !y) return VOC_ERR_INVALID;
+    if (ldk < c->K || y_len < (F - 1) * (int64_t)c->H + c->W || y_stride < y_len) return VOC_ERR_SIZE;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c, VOC_PRECISION_F32);
+        synthesis_signal_dev<float>(c, mag, ph_inc, ldk, F, C, phase_io, y, y_stride, y_len, (hipStream_t)stream);
+        return VOC_OK;
+    });
+}
+
+VOC_EXPORT int32_t voc_synthesis_mapped_f32_dev(voc_ctx *c, const float *mag, int64_t mag_frames, const int64_t *mag_rows,
+                                                const float *ph_inc, int64_t inc_frames, const int64_t *inc_rows, int64_t ldk,
+                                                int64_t F, int64_t C, float *phase_io, float *y, int64_t y_stride,
+                                                int64_t y_len, void *stream)
+{
+    if (!c || C < 0 || F < 0) return VOC_ERR_INVALID;
+    if (C == 0 || F == 0) return VOC_OK;
+    if (!mag || !ph_inc || !phase_io || !y) return VOC_ERR_INVALID;
+    if (ldk < c->K || y_len < (F - 1) * (int64_t)c->H + c->W || y_stride < y_len) return VOC_ERR_SIZE;
+    if ((mag_rows ? mag_frames < 1 : mag_frames != F) || (inc_rows ? inc_frames < 1 : inc_frames != F)) return VOC_ERR_SIZE;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c, VOC_PRECISION_F32);
+        synthesis_signal_dev<float>(c, mag, ph_inc, ldk, F, C, phase_io, y, y_stride, y_len, (hipStream_t)stream,
+                                    reinterpret_cast<const long long *>(mag_rows), mag_frames,
+                                    reinterpret_cast<const long long *>(inc_rows), inc_frames);
+        return VOC_OK;
+    });
+}
 
 VOC_EXPORT int32_t voc_profile_enable(voc_ctx *c, int32_t on)
 {

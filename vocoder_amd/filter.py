@@ -229,14 +229,19 @@ class BoundFilter:
 
     def apply(self, mag, ph_inc):
         """Host arrays (C, F, K) or (F, K): returns the filtered (mag, ph_inc) (new arrays)."""
-        mag, inc = _f64(mag).copy(), _f64(ph_inc).copy()
+        f32 = getattr(self.par, "precision", "f64") == "f32"
+        dt = np.float32 if f32 else np.float64
+        mag, inc = np.array(mag, dtype=dt, order="C"), np.array(ph_inc, dtype=dt, order="C")
         multi = mag.ndim == 3
         m3, i3 = (mag, inc) if multi else (mag[None], inc[None])
         for kind, v in self.parts:
             if kind == "chain":
                 c, f, _ = m3.shape
-                self.par.lib.check(self.par.lib.dll.voc_filter_apply(v._h, _p(m3), _p(i3), f, c), self.par.handle)
+                fn = self.par.lib.dll.voc_filter_apply_f32 if f32 else self.par.lib.dll.voc_filter_apply
+                self.par.lib.check(fn(v._h, _p(m3), _p(i3), f, c), self.par.handle)
             elif kind == "add":
+                if f32:
+                    raise ValueError("add_filters runs in double precision only")
                 self.frames_out(m3.shape[1])
                 (ma, ia), (mb, ib) = (b.apply(m3, i3) for b in v)
                 m3, i3 = np.empty_like(ma), np.empty_like(ia)
@@ -248,7 +253,10 @@ class BoundFilter:
         return (m3, i3) if multi else (m3[0], i3[0])
 
     def _run_chain(self, chain, mag, ph_inc, ldk, f, c, st, first_frame, first_channel):
-        self.par.lib.check(self.par.lib.dll.voc_filter_apply_at_dev(
+        import torch
+        # a float STFT (single-precision context) runs the same chain, widened on load and rounded once on store
+        fn = self.par.lib.dll.voc_filter_apply_f32_dev if mag.dtype == torch.float32 else self.par.lib.dll.voc_filter_apply_at_dev
+        self.par.lib.check(fn(
             chain._h, C.c_void_p(mag.data_ptr()), C.c_void_p(ph_inc.data_ptr()), ldk, f, c, int(first_frame),
             int(first_channel), st), self.par.handle)
 
@@ -295,6 +303,9 @@ class BoundFilter:
         return mag, mrows, ph_inc, irows, f
 
     def _apply_add(self, pair, mag, ph_inc, st, first_frame=0, first_channel=0):
+        import torch
+        if mag.dtype == torch.float32:
+            raise ValueError("add_filters runs in double precision only")
         self.frames_out(mag.shape[1])
         ma, ia = pair[0].apply_dev(mag.clone(), ph_inc.clone(), first_frame, first_channel)
         mag, ph_inc = pair[1].apply_dev(mag, ph_inc, first_frame, first_channel)
@@ -321,6 +332,8 @@ class BoundFilter:
             else:
                 if first_frame:
                     raise ValueError("play_speed renumbers the frames: it cannot follow a frame offset")
+                if mag.dtype == torch.float32:
+                    raise ValueError("single precision: play_speed goes through apply_dev_lazy (row maps)")
                 src = torch.from_numpy(play_speed_map(self.par, v, f)).to(mag.device)
                 fo = src.numel()
                 mo = torch.empty((c, fo, ldk), dtype=mag.dtype, device=mag.device)

@@ -22,6 +22,9 @@ class Stream:
         zero pre-pad, pushes in multiples of the hop, as many samples out as in."""
         self.par, self.channels = par, int(channels)
         self.chunk = par.H if chunk is None else int(chunk)
+        self.f32 = getattr(par, "precision", "f64") == "f32"      # a single-precision context: float state and samples
+        self.dtype = np.float32 if self.f32 else np.float64
+        self._sfx = "_f32" if self.f32 else ""
         fh, speed, after = None, None, None
         if filt is not None:
             kinds = [k for k, _ in filt.parts]
@@ -42,9 +45,13 @@ class Stream:
         if speed is not None:
             par.lib.check(par.lib.dll.voc_stream_set_play_speed(h, speed.numerator, speed.denominator, after), par.handle)
         if ana_phase is not None or syn_phase is not None:
-            a = np.zeros((self.channels, par.K)) if ana_phase is None else _f64(ana_phase).reshape(self.channels, par.K)
-            s = np.zeros((self.channels, par.K)) if syn_phase is None else _f64(syn_phase).reshape(self.channels, par.K)
-            par.lib.check(par.lib.dll.voc_stream_set_phases(h, _p(a), _p(s)), par.handle)
+            zero = np.zeros((self.channels, par.K), dtype=self.dtype)
+            a = zero if ana_phase is None else np.ascontiguousarray(ana_phase, dtype=self.dtype).reshape(self.channels, par.K)
+            s = zero if syn_phase is None else np.ascontiguousarray(syn_phase, dtype=self.dtype).reshape(self.channels, par.K)
+            par.lib.check(self._fn("voc_stream_set_phases")(h, _p(a), _p(s)), par.handle)
+
+    def _fn(self, name, dev: bool = False):
+        return getattr(self.par.lib.dll, name + self._sfx + ("_dev" if dev else ""))
 
     def set_filter(self, filt):
         """Swaps the per-frame filter chain between pushes (a new source of a concatenation)."""
@@ -59,22 +66,21 @@ class Stream:
 
     def push(self, x) -> np.ndarray:
         """x: (n,) for one channel or (C, n).  Returns the samples published by this push, (C, m)."""
-        x = _f64(x)
-        x2 = x.reshape(self.channels, -1)
+        x2 = np.ascontiguousarray(x, dtype=self.dtype).reshape(self.channels, -1)
         n = x2.shape[1]
         m = self.par.lib.dll.voc_stream_push_length(self._h, n)
-        y = np.empty((self.channels, max(m, 0)))
+        y = np.empty((self.channels, max(m, 0)), dtype=self.dtype)
         got = C.c_int64(0)
-        self.par.lib.check(self.par.lib.dll.voc_stream_push(self._h, _p(x2), n, n, _p(y), y.shape[1], y.shape[1],
-                                                            C.byref(got)), self.par.handle)
+        self.par.lib.check(self._fn("voc_stream_push")(self._h, _p(x2), n, n, _p(y), y.shape[1], y.shape[1],
+                                                       C.byref(got)), self.par.handle)
         assert got.value == m
         return y
 
     def flush(self) -> np.ndarray:
         m = self.par.lib.dll.voc_stream_flush_length(self._h)
-        y = np.empty((self.channels, max(m, 0)))
+        y = np.empty((self.channels, max(m, 0)), dtype=self.dtype)
         got = C.c_int64(0)
-        self.par.lib.check(self.par.lib.dll.voc_stream_flush(self._h, _p(y), y.shape[1], y.shape[1], C.byref(got)),
+        self.par.lib.check(self._fn("voc_stream_flush")(self._h, _p(y), y.shape[1], y.shape[1], C.byref(got)),
                            self.par.handle)
         return y
 
@@ -83,25 +89,25 @@ class Stream:
         import torch
         n = x.shape[1] if n is None else n
         m = self.par.lib.dll.voc_stream_push_length(self._h, n)
-        y = torch.empty((self.channels, max(m, 0)), dtype=torch.float64, device=x.device)
+        y = torch.empty((self.channels, max(m, 0)), dtype=torch.float32 if self.f32 else torch.float64, device=x.device)
         st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream) if x.is_cuda else None
         got = C.c_int64(0)
-        self.par.lib.check(self.par.lib.dll.voc_stream_push_dev(
+        self.par.lib.check(self._fn("voc_stream_push", dev=True)(
             self._h, C.c_void_p(x.data_ptr()), x.stride(0), n, C.c_void_p(y.data_ptr()), max(y.stride(0), y.shape[1]),
             y.shape[1], C.byref(got), st), self.par.handle)
         return y
 
     def phases(self):
-        a = np.empty((self.channels, self.par.K))
+        a = np.empty((self.channels, self.par.K), dtype=self.dtype)
         s = np.empty_like(a)
-        self.par.lib.check(self.par.lib.dll.voc_stream_get_phases(self._h, _p(a), _p(s)), self.par.handle)
+        self.par.lib.check(self._fn("voc_stream_get_phases")(self._h, _p(a), _p(s)), self.par.handle)
         return a, s
 
     def leftover(self) -> np.ndarray:
-        n = self.par.lib.dll.voc_stream_leftover(self._h, None, 0)
-        out = np.empty((self.channels, n))
+        n = self._fn("voc_stream_leftover")(self._h, None, 0)
+        out = np.empty((self.channels, n), dtype=self.dtype)
         if n:
-            self.par.lib.dll.voc_stream_leftover(self._h, _p(out), n)
+            self._fn("voc_stream_leftover")(self._h, _p(out), n)
         return out
 
     def close(self):

@@ -37,8 +37,8 @@ class VocoderParams:
 
     def __init__(self, frame_length: int, hop_size: int, window, device: int = 0, lib: Library | None = None,
                  precision: str = "f64"):
-        """precision "f32" makes a context of the single-precision variant: only the fused round trip
-        (`conduit.process_with`, `conduit.process_dev`) is available on it."""
+        """precision "f32" makes a context of the single-precision variant: the stage functions here and the
+        round trips of `conduit` (`process_with`, `process_dev`, `process_filter_dev` without a filter) run on it."""
         self.lib = lib or default_library()
         self.precision = precision
         if precision not in ("f64", "f32"):
@@ -245,24 +245,29 @@ def add_frames(*args, lib: Library | None = None):
     return mo, io
 
 
-def _stage_shapes(phase, data, inner):
-    data = np.ascontiguousarray(data, dtype=np.float64)
+def _stage_shapes(phase, data, inner, dtype=np.float64):
+    data = np.ascontiguousarray(data, dtype=dtype)
     if data.shape[-1] != inner:
         raise VocoderError(-5, f"size mismatch: expected last axis {inner}, got {data.shape[-1]}")
     multi = data.ndim == 3
     if not multi:
         data = data[None]
     c, f = data.shape[0], data.shape[1]
-    phase = np.array(phase, dtype=np.float64, copy=True).reshape(c, -1)
+    phase = np.array(phase, dtype=dtype, copy=True).reshape(c, -1)
     return phase, data, c, f, multi
+
+
+def _dtype_of(par):
+    return np.float32 if par.precision == "f32" else np.float64
 
 
 def analysis_stage(par, ph, frames):
     """analysisStage par ph frames -> (ph', [(mag, ph_inc)]) (Vocoder.hs:149-150).
     frames: (F, W) or (C, F, W); returns (phase, (mag, ph_inc)) with mag / ph_inc (.., F, K)."""
-    phase, frames, c, f, multi = _stage_shapes(ph, frames, par.W)
-    mag, inc = np.empty((c, f, par.K)), np.empty((c, f, par.K))
-    par._call("voc_analysis_stage", _p(phase), _p(frames), _p(mag), _p(inc), c, f)
+    dt = _dtype_of(par)
+    phase, frames, c, f, multi = _stage_shapes(ph, frames, par.W, dt)
+    mag, inc = np.empty((c, f, par.K), dtype=dt), np.empty((c, f, par.K), dtype=dt)
+    par._call("voc_analysis_stage_f32" if dt is np.float32 else "voc_analysis_stage", _p(phase), _p(frames), _p(mag), _p(inc), c, f)
     if not multi:
         return phase[0], (mag[0], inc[0])
     return phase, (mag, inc)
@@ -271,10 +276,11 @@ def analysis_stage(par, ph, frames):
 def synthesis_stage(par, ph, stft):
     """synthesisStage par ph stft -> (ph', frames) (Vocoder.hs:177-178)."""
     mag, inc = stft
-    phase, mag, c, f, multi = _stage_shapes(ph, mag, par.K)
-    inc = np.ascontiguousarray(inc, dtype=np.float64).reshape(c, f, par.K)
-    frames = np.empty((c, f, par.W))
-    par._call("voc_synthesis_stage", _p(phase), _p(mag), _p(inc), _p(frames), c, f)
+    dt = _dtype_of(par)
+    phase, mag, c, f, multi = _stage_shapes(ph, mag, par.K, dt)
+    inc = np.ascontiguousarray(inc, dtype=dt).reshape(c, f, par.K)
+    frames = np.empty((c, f, par.W), dtype=dt)
+    par._call("voc_synthesis_stage_f32" if dt is np.float32 else "voc_synthesis_stage", _p(phase), _p(mag), _p(inc), _p(frames), c, f)
     if not multi:
         return phase[0], frames[0]
     return phase, frames
@@ -282,12 +288,12 @@ def synthesis_stage(par, ph, stft):
 
 def analysis_block(par, prev_ph, frame):
     """analysisBlock par prev_ph vec -> (ph, (mag, ph_inc)) (Vocoder.hs:153-154)."""
-    ph, (mag, inc) = analysis_stage(par, prev_ph, _f64(frame)[None, :])
+    ph, (mag, inc) = analysis_stage(par, prev_ph, np.asarray(frame)[None, :])
     return ph, (mag[0], inc[0])
 
 
 def synthesis_block(par, ph, stft):
     """synthesisBlock par ph (mag, ph_inc) -> (ph', frame) (Vocoder.hs:181-182)."""
     mag, inc = stft
-    ph2, frames = synthesis_stage(par, ph, (_f64(mag)[None, :], _f64(inc)[None, :]))
+    ph2, frames = synthesis_stage(par, ph, (np.asarray(mag)[None, :], np.asarray(inc)[None, :]))
     return ph2, frames[0]
