@@ -172,3 +172,28 @@ foreign import ccall safe "voc_filter_apply_at_dev" c_voc_filter_apply_at_dev
 foreign import ccall safe "voc_binary_frames_dev" c_voc_binary_frames_dev
     :: Ptr VocCtx -> Int32 -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Int64
     -> Ptr () -> IO Int32
+
+-- * Single-precision forms (contexts created with precision 1; every array is Float).  Argument lists as the
+--   double forms above.
+foreign import ccall safe "voc_roundtrip_f32" c_voc_roundtrip_f32
+    :: Ptr VocCtx -> Ptr Float -> Int64 -> Int64 -> Int64 -> Int64 -> Ptr Float -> Int64
+    -> Ptr Float -> Ptr Float -> Ptr Float -> Int64 -> IO Int32
+foreign import ccall safe "voc_analysis_stage_f32" c_voc_analysis_stage_f32
+    :: Ptr VocCtx -> Ptr Float -> Ptr Float -> Ptr Float -> Ptr Float -> Int64 -> Int64 -> IO Int32
+foreign import ccall safe "voc_synthesis_stage_f32" c_voc_synthesis_stage_f32
+    :: Ptr VocCtx -> Ptr Float -> Ptr Float -> Ptr Float -> Ptr Float -> Int64 -> Int64 -> IO Int32
+foreign import ccall safe "voc_filter_apply_f32" c_voc_filter_apply_f32
+    :: Ptr VocFilter -> Ptr Float -> Ptr Float -> Int64 -> Int64 -> IO Int32
+foreign import ccall safe "voc_stream_set_phases_f32" c_voc_stream_set_phases_f32
+    :: Ptr VocStream -> Ptr Float -> Ptr Float -> IO Int32
+foreign import ccall safe "voc_stream_get_phases_f32" c_voc_stream_get_phases_f32
+    :: Ptr VocStream -> Ptr Float -> Ptr Float -> IO Int32
+foreign import ccall safe "voc_stream_leftover_f32" c_voc_stream_leftover_f32
+    :: Ptr VocStream -> Ptr Float -> Int64 -> IO Int64
+foreign import ccall safe "voc_stream_push_f32" c_voc_stream_push_f32
+    :: Ptr VocStream -> Ptr Float -> Int64 -> Int64 -> Ptr Float -> Int64 -> Int64 -> Ptr Int64 -> IO Int32
+foreign import ccall safe "voc_stream_flush_f32" c_voc_stream_flush_f32
+    :: Ptr VocStream -> Ptr Float -> Int64 -> Int64 -> Ptr Int64 -> IO Int32
+-- | playSpeed inside a stream: num, den, chain that runs on the yielded frames (or nullPtr)
+foreign import ccall safe "voc_stream_set_play_speed" c_voc_stream_set_play_speed
+    :: Ptr VocStream -> Int64 -> Int64 -> Ptr VocFilter -> IO Int32
