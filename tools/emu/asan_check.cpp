@@ -1,6 +1,7 @@
 // asan_check.cpp -- DEVELOPMENT HARNESS: the C-ABI library compiled for the host (hip_emu.h) into one
 // executable under AddressSanitizer / UBSan, driven through a set of scenarios that cover every
-// kernel family (radix kernels, fast kernels, chirp-z, filters, streaming, single precision).
+// kernel family (radix kernels, fast kernels, chirp-z in LDS and through device memory, filters, streaming with
+// playSpeed, the context-free functions, the single-precision forms).
 //   make -C tools/emu asan && tools/emu/asan_check
 #include "../../vocoder_amd/csrc/vocoder_hip.cpp"
 
@@ -70,6 +71,39 @@ static int scenario(int n, int w, int h, int channels, int frames, int chunk)
     int64_t got = 0;
     OK(voc_stream_flush(st, out.data(), cap, cap, &got));
     OK(voc_stream_destroy(st));
+
+    // playSpeed 3/2 between two chains, pushed in pieces
+    voc_filter *after = nullptr;
+    OK(voc_filter_create(ctx, 48000.0 / n, &after));
+    const double q5[] = {0.5};
+    OK(voc_filter_append(after, VOC_FILTER_AMPLIFY, q5, 1));
+    OK(voc_stream_create(ctx, channels, chunk, flt, &st));
+    OK(voc_stream_set_play_speed(st, 3, 2, after));
+    for (int64_t pos = 0; pos < len;) {
+        const int64_t m = std::min<int64_t>(len - pos, 1 + (int64_t)(rng() % (3 * h + 1)));
+        piece.assign((size_t)channels * m, 0.0);
+        for (int c = 0; c < channels; ++c) std::copy_n(&x[(size_t)c * len + pos], m, &piece[(size_t)c * m]);
+        const int64_t cap2 = voc_stream_push_length(st, m);
+        out.assign((size_t)channels * (cap2 > 0 ? cap2 : 1), 0.0);
+        OK(voc_stream_push(st, piece.data(), m, m, out.data(), cap2, cap2, &got));
+        pos += m;
+    }
+    const int64_t cap3 = voc_stream_flush_length(st);
+    out.assign((size_t)channels * (cap3 > 0 ? cap3 : 1), 0.0);
+    OK(voc_stream_flush(st, out.data(), cap3, cap3, &got));
+    OK(voc_stream_destroy(st));
+    OK(voc_filter_destroy(after));
+
+    // the FFT layer and the functions with the reference's own argument lists
+    std::vector<double> spec((size_t)2 * k), frame0(fr.begin(), fr.begin() + w), m1((size_t)k), p1((size_t)k), i1((size_t)k),
+        zero((size_t)k, 0.0), spec2((size_t)2 * k), back((size_t)w);
+    OK(voc_do_fft(ctx, frame0.data(), spec.data(), 1));
+    OK(voc_analysis_step_hn(h, n, k, zero.data(), spec.data(), p1.data(), m1.data(), i1.data(), 1));
+    OK(voc_synthesis_step_h(h, k, zero.data(), m1.data(), i1.data(), p1.data(), spec2.data(), 1));
+    OK(voc_do_ifft(ctx, spec2.data(), back.data(), 1));
+    OK(voc_frame_from_complex(spec.data(), m1.data(), p1.data(), k));
+    OK(voc_frame_to_complex(m1.data(), p1.data(), spec2.data(), k));
+    OK(voc_add_frames_n(m1.data(), i1.data(), m1.data(), i1.data(), m1.data(), i1.data(), k));
     OK(voc_filter_destroy(flt));
     OK(voc_ctx_destroy(ctx));
     std::printf("ok  N=%d W=%d H=%d C=%d F=%lld\n", n, w, h, channels, (long long)f);
@@ -87,6 +121,34 @@ static int scenario_f32(int n, int h, int channels, int frames)
     std::vector<float> y((size_t)channels * olen), left((size_t)channels * (keep ? keep : 1)), a((size_t)channels * k, 0.f),
         s((size_t)channels * k, 0.f);
     OK(voc_roundtrip_f32(ctx, x.data(), len, len, channels, h, y.data(), olen, a.data(), s.data(), left.data(), keep));
+    // stage level, a filter chain on the float STFT, and a stream
+    std::vector<float> fr((size_t)channels * f * n, 0.125f), mag((size_t)channels * f * k), inc(mag.size()), ph((size_t)channels * k, 0.f);
+    OK(voc_analysis_stage_f32(ctx, ph.data(), fr.data(), mag.data(), inc.data(), channels, f));
+    voc_filter *flt = nullptr;
+    OK(voc_filter_create(ctx, 48000.0 / n, &flt));
+    const double q1[] = {1.5}, q2[] = {7.0};
+    OK(voc_filter_append(flt, VOC_FILTER_PITCH_SHIFT_INTERPOLATE, q1, 1));
+    OK(voc_filter_append(flt, VOC_FILTER_RANDOM_PHASE, q2, 1));
+    OK(voc_filter_apply_f32(flt, mag.data(), inc.data(), f, channels));
+    std::fill(ph.begin(), ph.end(), 0.f);
+    OK(voc_synthesis_stage_f32(ctx, ph.data(), mag.data(), inc.data(), fr.data(), channels, f));
+    voc_stream *st = nullptr;
+    OK(voc_stream_create(ctx, channels, h, flt, &st));
+    OK(voc_stream_set_play_speed(st, 2, 1, nullptr));
+    int64_t got = 0;
+    for (int64_t pos = 0; pos < len; pos += 3 * h + 1) {
+        const int64_t m = std::min<int64_t>(len - pos, 3 * h + 1);
+        std::vector<float> piece((size_t)channels * m, 0.25f);
+        const int64_t cap = voc_stream_push_length(st, m);
+        std::vector<float> out((size_t)channels * (cap > 0 ? cap : 1));
+        OK(voc_stream_push_f32(st, piece.data(), m, m, out.data(), cap, cap, &got));
+    }
+    const int64_t cap = voc_stream_flush_length(st);
+    std::vector<float> out((size_t)channels * (cap > 0 ? cap : 1));
+    OK(voc_stream_flush_f32(st, out.data(), cap, cap, &got));
+    OK(voc_stream_get_phases_f32(st, a.data(), s.data()));
+    OK(voc_stream_destroy(st));
+    OK(voc_filter_destroy(flt));
     OK(voc_ctx_destroy(ctx));
     std::printf("ok  f32 N=%d\n", n);
     return 0;
@@ -138,6 +200,7 @@ int main()
     bad |= scenario_dev(2048, 512, 2, 6);          // registers for the accumulated phases, rows loaded at use
     bad |= scenario(2048, 2048, 512, 1, 6, 512);
     bad |= scenario_dev(100, 20, 1, 6);            // chirp-z
+    bad |= scenario(4100, 3000, 1000, 1, 3, 1000); // chirp-z through device memory (two interleaved 8192-point transforms)
     bad |= scenario_f32(64, 16, 2, 9);
     bad |= scenario_f32(1024, 256, 1, 7);
     std::printf(bad ? "FAILURES\n" : "all scenarios ran\n");
