@@ -91,8 +91,8 @@ def cpu_baseline_all_cores(window, x_sample, cores):
 
 def relaunch_under_torchrun(n):
     """`python bench.py --gpus N` called plainly: start the N ranks as child processes of a parent that
-    has not touched a GPU, pass their output through (rank 0 prints the JSON line) and exit with
-    the launcher's status."""
+    has not touched a GPU and exit with the launcher's status.  Rank 0's JSON line is the only thing
+    that reaches stdout; whatever else the ranks or the communication library print there goes to stderr."""
     import socket
     import subprocess
     s = socket.socket()
@@ -101,7 +101,12 @@ def relaunch_under_torchrun(n):
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    raise SystemExit(subprocess.call(cmd))
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in child.stdout:
+        is_result = line.startswith("{") and '"metric"' in line
+        (sys.stdout if is_result else sys.stderr).write(line)
+        (sys.stdout if is_result else sys.stderr).flush()
+    raise SystemExit(child.wait())
 
 
 def timeshard_mode(args, world, rank, dev, red_dev, D):
