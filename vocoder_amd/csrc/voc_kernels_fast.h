@@ -40,6 +40,10 @@
 #define VOC_SYN_FENCE 1
 #endif
 
+#ifndef VOC_LAST_IN_REGS
+#define VOC_LAST_IN_REGS 1  // the transform's last results (analysis, synthesis) and first inputs (synthesis) stay in registers where the same thread uses them
+#endif
+
 #ifndef VOC_POLAR_UNROLL
 #define VOC_POLAR_UNROLL 1  // bin pairs in flight in the analysis polar loop
 #endif
@@ -318,11 +322,25 @@ VOC_DEV void pass4_store(C2 *lds, int tid, const C2 (&v)[8])
     }
 }
 
+// Where the results of the last pass sit in a thread's registers.  A Stockham transform ends in natural
+// order, and the last pass leaves element tid + n T (n = 0..7) of the result with thread tid: butterfly
+// q of the thread (q < NB4) produces the elements tid + q T + j NB4 T, so element n is v[(n mod NB4) R4 +
+// n / NB4] (v[n] where the third pass is the last).
+template <int LOG2M>
+VOC_DEV constexpr int nat_idx(int n)
+{
+    constexpr int R4 = FastCfg<LOG2M>::R4, NB4 = FastCfg<LOG2M>::NB4;
+    return R4 > 1 ? (n % NB4) * R4 + n / NB4 : n;
+}
+
 // Passes 2..4 of the transform whose first-pass butterflies are already in v.  `prefetch` is
 // called once, after the last butterfly and before the last store: the place for the caller's
 // next-frame loads.
+// KEEP_LAST: the results of the last pass are not written back: they stay in v, element tid + n T at
+// v[nat_idx(n)], and the caller puts a barrier between this call and its next write to the transform's
+// LDS area (other threads may still be reading the last pass' input).
 // twl: optional table in LDS, the twiddle rows of the passes at stride 8 (56 entries) and 64 (448 entries).
-template <int LOG2M, class C2, class Prefetch>
+template <int LOG2M, bool KEEP_LAST = false, class C2, class Prefetch>
 VOC_DEV void fft_after_first(C2 *lds, const FastTw<LOG2M, C2> &t, int tid, C2 (&v)[8], Prefetch prefetch,
                              const C2 *twl = nullptr)
 {
@@ -342,12 +360,14 @@ VOC_DEV void fft_after_first(C2 *lds, const FastTw<LOG2M, C2> &t, int tid, C2 (&
     else twiddle8(v, t.c);
     dft<8>(v);
     if (R4 == 1) prefetch();
+    if (R4 == 1 && KEEP_LAST) return;
     __syncthreads();
     store8<LOG2M, 64>(lds, tid, v);
     __syncthreads();
     if (R4 > 1) {
         pass4_compute<LOG2M>(lds, tid, t, v);
         prefetch();
+        if (KEEP_LAST) return;
         __syncthreads();
         pass4_store<LOG2M>(lds, tid, v);
         __syncthreads();
@@ -432,7 +452,11 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
             v[j] = mk2(ws[u].x * xs[u].x, ws[u].y * xs[u].y);
         }
         dft<8>(v);
-        fft_after_first<LOG2M>(lds, tw, tid, v, [&]() {
+        // The last pass leaves element tid + n T of the spectrum with thread tid, and the thread's four bin
+        // pairs are (tid + m T, M - tid - m T): the first of each pair is already here (n = 0..3), the second
+        // is the n = 7 - m of thread T - tid.  So only the upper four results go through LDS.
+        constexpr bool KEEP = VOC_LAST_IN_REGS != 0;
+        fft_after_first<LOG2M, KEEP>(lds, tw, tid, v, [&]() {
             if (f + 1 < f1) {  // the pairs of the next frame that are not already in registers, and the window again
                 const R *fr = xc + (f + 1) * a.frame_stride;
                 const int lp = opaque_int(tid);
@@ -456,6 +480,14 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
         const bool self0 = lt == 0;
         const unsigned pe0 = self0 ? M / 2 : (unsigned)lt;      // first pair: bins pe0 and M - pe0
         const C2 *zlo = lds + lds_sw(lt), *zhi = lds + lds_sw(M - lt);
+        if constexpr (KEEP) {
+            __syncthreads();  // the last pass' input has been read by everyone
+            C2 *zw = lds + lds_sw(lt);
+#pragma unroll
+            for (int n = 4; n < 8; ++n) zw[n * T] = v[nat_idx<LOG2M>(n)];
+            if (tid == 0) lds[0] = v[nat_idx<LOG2M>(0)];  // Z[0]: the DC / Nyquist pair, read by two other threads
+            __syncthreads();
+        }
         // byte offsets of the pair's bins in an STFT row and in the phase array: slot 0 has its own, slots
         // 1..3 sit at +-(m - 2) T elements around one offset each (immediates of the memory instructions)
         constexpr int SZ = (int)sizeof(R);
@@ -469,11 +501,17 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
             const int ipe = m == 0 ? 0 : (m - 2) * T * SZ, iq = -ipe;
             C2 P, Q, w;
             if (m == 0) {
-                P = lds[lds_sw(pe)];
+                if constexpr (KEEP) {  // thread 0's self-paired bin M/2 is its own element 4 T
+                    const C2 va = v[nat_idx<LOG2M>(0)], vb = v[nat_idx<LOG2M>(4)];
+                    P = mk2(self0 ? vb.x : va.x, self0 ? vb.y : va.y);
+                } else {
+                    P = lds[lds_sw(pe)];
+                }
                 Q = lds[lds_sw(q)];
                 w = split_tw(tw.s, 0, self0);
             } else {
-                P = zlo[m * T];
+                if constexpr (KEEP) P = v[nat_idx<LOG2M>(m)];
+                else P = zlo[m * T];
                 Q = zhi[-m * T];
                 w = split_tw(tw.s, m, false);
             }
@@ -640,6 +678,11 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
         // (lds_sw is additive in multiples of 64, and T is one)
         const bool self0 = lt == 0;
         C2 *zlo = lds + lds_sw(lt), *zhi = lds + lds_sw(M - lt);
+        // The first pass reads the elements tid + j T.  Those with j < 4 are this thread's own Z[pe]; the
+        // others are the Z[M - pe] of thread T - tid (thread 0: its own).  Only the latter go through LDS.
+        constexpr bool KEEP_IN = VOC_LAST_IN_REGS != 0;
+        constexpr bool KEEP_OUT = VOC_LAST_IN_REGS != 0 && OLA;  // ... and the overlap-add wants tid + n T, which the last pass leaves here
+        C2 za[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const bool self = m == 0 && self0;
@@ -658,11 +701,12 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
             }
             C2 Za, Zb;
             merge_pair(A, B, split_tw(tw.s, m, self), Za, Zb);
+            za[m] = Za;
             if (m == 0) {
-                lds[lds_sw(pe)] = Za;
+                if constexpr (!KEEP_IN) lds[lds_sw(pe)] = Za;
                 lds[lds_sw(q)] = Zb;
             } else {
-                zlo[m * T] = Za;
+                if constexpr (!KEEP_IN) zlo[m * T] = Za;
                 zhi[-m * T] = Zb;
             }
 #if VOC_SYN_FENCE
@@ -680,14 +724,24 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
                 php[0] = ph0;
                 php[M] = phm;
             }
-            lds[0] = mk2(A.x - B.x, A.x + B.x);
+            const C2 z0 = mk2(A.x - B.x, A.x + B.x);
+            if constexpr (KEEP_IN) za[0] = z0;  // element 0; thread 0's slot 0 was bin M/2, which it reads back as element 4 T
+            else lds[0] = z0;
         }
         wave_prio<VOC_PRIO_SYN_T, LOG2M>();
         __syncthreads();
         C2 v[8];
-        load8<LOG2M>(lds, lt, v);
+        if constexpr (KEEP_IN) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = za[j];
+                v[j + 4] = zlo[(j + 4) * T];
+            }
+        } else {
+            load8<LOG2M>(lds, lt, v);
+        }
         dft<8>(v);
-        fft_after_first<LOG2M>(lds, tw, lt, v, [&]() {
+        fft_after_first<LOG2M, KEEP_OUT>(lds, tw, lt, v, [&]() {
             if (ROW_PF && f + 1 < f1) load_row(f + 1, lt);
         }, TW_LDS ? twl : nullptr);
         // lds[pad(m)] = swapped z[m]: v[2m] = z.y / N, v[2m+1] = z.x / N.  frame[i] = w[i] * v[(i + off + N/2) mod N]
@@ -705,7 +759,8 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 const int e = (j * T + M / 2) & (M - 1);
-                zv[j] = zb[e];
+                if constexpr (KEEP_OUT) zv[j] = v[nat_idx<LOG2M>((j + 4) & 7)];
+                else zv[j] = zb[e];
             }
             C2 cur[NP];
 #pragma unroll
