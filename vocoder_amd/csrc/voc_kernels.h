@@ -51,6 +51,7 @@ struct ParamsT {
     int hop_pow2;  // H is a power of two: x / H == x * (1/H) exactly
     R hop_d, inv_hop, inv_n;
     const R *window;       // [W]
+    const R *window_n;     // [W]  window[i] * (1/N): exact where N is a power of two (contexts only; null elsewhere)
     const cplx<R> *twP;    // [M-1]    per-pass twiddles, see fft_passes
     const cplx<R> *twS;    // [M/2+1]  exp(-2 pi i k / N)
     double omega1;         // 2 pi H / N when H and N are powers of two (the scaling is then exact), else 0
@@ -232,11 +233,19 @@ VOC_DEV double approx_rcp(double b)
 // (relative error below 2^-24 on gfx950, measured over a dense sweep by tools/ubench/seed_precision.hip),
 // one Newton step (2^-48), one residual correction of the quotient -- on that sweep the bits of the
 // correctly rounded quotient.
+// LEAN (here and in sqrt_scaled, atan_poly, hs_polar): the form the fused kernels use.  It stops one
+// step earlier -- no residual correction of the quotient and of the square root (2^-48 instead of
+// correctly rounded), a degree-8 instead of a degree-10 arctangent polynomial (4e-15 instead of 5e-18
+// before rounding) -- which leaves magnitudes within 3e-15 relative and phases within 3e-14 rad of the
+// full form's (measured against the CPU restatement), five orders below the 1e-9 the path is held to,
+// for six instructions per bin less.
+template <bool LEAN = false>
 VOC_DEV double div_pos(double a, double b)
 {
     double r = approx_rcp(b);
     r = fma(fma(-b, r, 1.0), r, r);
     const double q = a * r;
+    if (LEAN) return q;
     return fma(fma(-b, q, a), r, q);
 }
 
@@ -258,6 +267,7 @@ VOC_DEV int frexp_exponent(double v)  // exponent e with |v| = m 2^e, 0.5 <= m <
 // of which changes a bit on this domain (tools/ubench/seed_precision.hip).  For s = 0 the seed is taken of
 // a tiny positive number instead: it stays finite, every product with s is an exact zero and the
 // result is 0 without a test.
+template <bool LEAN = false>
 VOC_DEV double sqrt_scaled(double s)
 {
 #ifdef VOC_EMU
@@ -268,6 +278,7 @@ VOC_DEV double sqrt_scaled(double s)
     double h = 0.5 * y;
     const double r = fma(-h, g, 0.5);
     g = fma(g, r, g);
+    if (LEAN) return g;
     h = fma(h, r, h);
     return fma(fma(-g, g, s), h, g);
 #endif
@@ -290,9 +301,22 @@ VOC_DEV double horner(double p, double z, double c)
 
 // atan(t) = t + t z P(z), z = t^2, for |t| <= tan(pi/8): degree-10 minimax P (tools/gen_poly.py),
 // relative error 5e-18 before rounding.
+template <bool LEAN = false>
 VOC_DEV double atan_poly(double t)
 {
     const double z = t * t;
+    if (LEAN) {  // degree 8 (tools/gen_poly.py), relative error 3.9e-15 before rounding
+        double q = -0x1.bf5790a65fcfbp-6;
+        q = horner(q, z, 0x1.a7d43558287d4p-5);
+        q = horner(q, z, -0x1.0c6176a21253cp-4);
+        q = horner(q, z, 0x1.3a9faa15e1c1cp-4);
+        q = horner(q, z, -0x1.745668abcbcd7p-4);
+        q = horner(q, z, 0x1.c71c3a088a42bp-4);
+        q = horner(q, z, -0x1.249248af9e3c5p-3);
+        q = horner(q, z, 0x1.99999998dc43dp-3);
+        q = horner(q, z, -0x1.55555555553c1p-2);
+        return fma(t * z, q, t);
+    }
     double p = -0x1.3b08efe0aa3adp-6;
     p = horner(p, z, 0x1.41bf291d28cbdp-5);
     p = horner(p, z, -0x1.a0bb5679f2cabp-5);
@@ -331,19 +355,20 @@ VOC_DEV double atan_poly(double t)
 // The zero bin needs no test of its own: its divisor is replaced by a tiny positive number, so the
 // quotient is 0, and "x negative" is decided by x < 0, false for -0.  The result is a zero with the
 // sign of y (the reference's is +0 for every zero bin).
+template <bool LEAN = false>
 VOC_DEV void hs_polar(double x, double y, double &mag, double &ph)
 {
     const double ax = fabs(x), ay = fabs(y);
     const int e = frexp_exponent(fmax(ax, ay));
     const double sx = ldexp(ax, -e), sy = ldexp(ay, -e);
     const double a = sx * sx, b = sy * sy;
-    const double r = sqrt_scaled(a + b);  // in [0.5, 1.42), or 0
+    const double r = sqrt_scaled<LEAN>(a + b);  // in [0.5, 1.42), or 0
     mag = ldexp(r, e);
     const double d0 = r + sx;             // in [0.5, 2.42), or 0
     const double f = (sy > 0.41421356237309503 * d0) ? 1.0 : 0.0;
     const double num = fma(-f, d0, sy);
     const double den = fmax(fma(f, sy, d0), 0x1p-1000);  // in [0.5, 3.84) unless the bin is zero
-    const double half = fma(f, 0.78539816339744828, atan_poly(div_pos(num, den)));
+    const double half = fma(f, 0.78539816339744828, atan_poly<LEAN>(div_pos<LEAN>(num, den)));
     const double s2 = (x < 0.0) ? -2.0 : 2.0;
     const double off = fma(-s2, 0.78539816339744828, 1.5707963267948966);  // 0 or pi, exactly
     ph = copysign(fma(s2, half, off), y);
@@ -425,14 +450,23 @@ VOC_DEV void fast_sincos(double x, double *sn, double *cs)
 // correction -- no compare, no select.  Only a remainder within an ulp of 2 pi (probability
 // ~2^-52 per call) can still be taken for a full turn: the result is then one turn off, i.e. -pi - tiny
 // instead of pi - tiny, the same angle.
+#ifndef VOC_WRAP8
+#define VOC_WRAP8 1
+#endif
 VOC_DEV double hs_wrap(double e)
 {
     const double n = e + kPi;
     const double f0 = floor(n * kInvTwoPi);
     const double r0 = fma(-f0, kTwoPi, n);
+#if VOC_WRAP8
+    // the corrected remainder itself: n - f 2pi in one rounding where the reference's n - fl(f 2pi) has
+    // two (they differ by at most an ulp of n: 5e-13 rad at bin 2048), with the same floor f
+    return fma(-floor(r0 * kInvTwoPi), kTwoPi, r0) - kPi;
+#else
     const double f = f0 + floor(r0 * kInvTwoPi);
     const double t = f * kTwoPi;
     return (n - t) - kPi;
+#endif
 }
 
 // ---- single precision: the same definitions on float.
@@ -458,6 +492,7 @@ VOC_DEV int frexp_exponent(float v)
 
 // Same construction as the double version: shared power-of-two scaling, one division placed
 // after the fold at tan(pi/8), atan(t) = t + t z P(z) with a degree-4 minimax P (error 2.5e-9).
+template <bool LEAN = false>
 VOC_DEV void hs_polar(float x, float y, float &mag, float &ph)
 {
     const float ax = fabsf(x), ay = fabsf(y);

@@ -40,6 +40,26 @@
 #define VOC_SYN_FENCE 1
 #endif
 
+#ifndef VOC_SYN_WIN_EARLY
+#define VOC_SYN_WIN_EARLY 8  // synthesis: how many of the eight window pairs of the overlap-add are requested before the transform's last pass
+#endif
+
+#ifndef VOC_TW_OPAQUE_TOP
+#define VOC_TW_OPAQUE_TOP 1  // twiddle bases marked changed once per frame, in place, instead of a marked copy at every use
+#endif
+
+#ifndef VOC_SYN_WIN_SCALED
+#define VOC_SYN_WIN_SCALED 1  // overlap-add multiplies by window / N (exact: N is a power of two) instead of scaling every sample by 1/N first
+#endif
+
+#ifndef VOC_ANA_PHP_PAIRS
+#define VOC_ANA_PHP_PAIRS 1  // analysis: previous phases of a bin pair side by side in LDS (one 16-byte access per pair)
+#endif
+
+#ifndef VOC_POLAR_LEAN
+#define VOC_POLAR_LEAN 1  // analysis: the shorter polar conversion (see div_pos in voc_kernels.h)
+#endif
+
 #ifndef VOC_LAST_IN_REGS
 #define VOC_LAST_IN_REGS 1  // the transform's last results (analysis, synthesis) and first inputs (synthesis) stay in registers where the same thread uses them
 #endif
@@ -190,6 +210,21 @@ struct FastTw {
     C2 s;                              // exp(-2 pi i tid / N): base of the split twiddles
 };
 
+// Called at the top of every frame: everything derived from the bases is then recomputed per frame
+// (a few dozen multiplications) instead of living in 84 registers across the loop -- and, unlike a
+// marked copy at each use, costs no instruction.
+template <int LOG2M, class C2>
+VOC_DEV void fast_tw_touch(FastTw<LOG2M, C2> &t)
+{
+    if (VOC_TW_OPAQUE_TOP) {
+        opaque(t.b);
+        opaque(t.c);
+#pragma unroll
+        for (int q = 0; q < FastCfg<LOG2M>::NB4; ++q) opaque(t.d[q]);
+        opaque(t.s);
+    }
+}
+
 template <int LOG2M, class R>
 VOC_DEV void fast_tw_init(const ParamsT<R> &p, int tid, FastTw<LOG2M, cplx<R>> &t)
 {
@@ -207,7 +242,7 @@ template <class C2>
 VOC_DEV C2 split_tw(C2 s, int m, bool self_pair)
 {
     using R = decltype(s.x);
-    opaque(s);
+    if (!VOC_TW_OPAQUE_TOP) opaque(s);
     const R cr = (R)(m == 0 ? 1.0 : (m == 1 ? 0.92387953251128673848 : (m == 2 ? 0.70710678118654752440 : 0.38268343236508977173)));
     const R ci = (R)(m == 0 ? 0.0 : (m == 1 ? -0.38268343236508977173 : (m == 2 ? -0.70710678118654752440 : -0.92387953251128673848)));
     const C2 w = cmul(s, mk2(cr, ci));  // m == 0: s * (1, 0) = s exactly
@@ -249,7 +284,7 @@ VOC_DEV void store8(C2 *lds, int tid, const C2 (&v)[8])
 template <class C2>
 VOC_DEV void twiddle8(C2 (&v)[8], C2 w1)
 {
-    opaque(w1);
+    if (!VOC_TW_OPAQUE_TOP) opaque(w1);
     const C2 w2 = csqr(w1);
     v[1] = cmul(v[1], w1);
     v[2] = cmul(v[2], w2);
@@ -284,7 +319,7 @@ VOC_DEV void pass4_compute(const C2 *lds, int tid, const FastTw<LOG2M, C2> &t, C
 #pragma unroll
             for (int j = 0; j < R4; ++j) w[j] = src[j * NBF];
             C2 pw = t.d[q];
-            opaque(pw);
+            if (!VOC_TW_OPAQUE_TOP) opaque(pw);
             w[1] = cmul(w[1], pw);
             if constexpr (R4 >= 4) {
                 const C2 w2 = csqr(pw);
@@ -340,9 +375,11 @@ VOC_DEV constexpr int nat_idx(int n)
 // v[nat_idx(n)], and the caller puts a barrier between this call and its next write to the transform's
 // LDS area (other threads may still be reading the last pass' input).
 // twl: optional table in LDS, the twiddle rows of the passes at stride 8 (56 entries) and 64 (448 entries).
-template <int LOG2M, bool KEEP_LAST = false, class C2, class Prefetch>
+// `early` is called once before the last pass reads its input: the place for loads that the caller uses right after the transform.
+struct NoHook { VOC_DEV void operator()() const {} };
+template <int LOG2M, bool KEEP_LAST = false, class C2, class Prefetch, class Early = NoHook>
 VOC_DEV void fft_after_first(C2 *lds, const FastTw<LOG2M, C2> &t, int tid, C2 (&v)[8], Prefetch prefetch,
-                             const C2 *twl = nullptr)
+                             const C2 *twl = nullptr, Early early = Early())
 {
     constexpr int R4 = FastCfg<LOG2M>::R4;
     __syncthreads();
@@ -355,6 +392,7 @@ VOC_DEV void fft_after_first(C2 *lds, const FastTw<LOG2M, C2> &t, int tid, C2 (&
     __syncthreads();
     store8<LOG2M, 8>(lds, tid, v);
     __syncthreads();
+    if (R4 == 1) early();
     load8<LOG2M>(lds, tid, v);
     if (twl) twiddle8_tab(v, twl + 56 + (tid & 63), 64);
     else twiddle8(v, t.c);
@@ -365,6 +403,7 @@ VOC_DEV void fft_after_first(C2 *lds, const FastTw<LOG2M, C2> &t, int tid, C2 (&
     store8<LOG2M, 64>(lds, tid, v);
     __syncthreads();
     if (R4 > 1) {
+        early();
         pass4_compute<LOG2M>(lds, tid, t, v);
         prefetch();
         if (KEEP_LAST) return;
@@ -396,9 +435,22 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
     const long long f1 = (f0 + a.tile_len < a.F) ? f0 + a.tile_len : a.F;
     const R *xc = a.x + c * a.chan_stride;
 
+    // PAIRS: the previous phases of pair slot m of thread t (bins pe = t + m T -- thread 0, slot 0: M/2 --
+    // and M - pe) are the two halves of the 16-byte element t + m T; element 4 T holds bins 0 and M.
+    constexpr bool PAIRS = VOC_ANA_PHP_PAIRS != 0;
+    C2 *php2 = reinterpret_cast<C2 *>(php);
     if (f0 == 0) {
         const R *pi = a.phase_in + c * p.K;
-        for (int k = tid; k < p.K; k += T) php[k] = pi[k];
+        if constexpr (PAIRS) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int pe = (m == 0 && tid == 0) ? M / 2 : tid + m * T;
+                php2[tid + m * T] = mk2(pi[pe], pi[M - pe]);
+            }
+            if (tid == 0) php2[4 * T] = mk2(pi[0], pi[M]);
+        } else {
+            for (int k = tid; k < p.K; k += T) php[k] = pi[k];
+        }
     }
     // (ownership of php differs between this fill and the loop below; the barriers inside the
     //  FFT separate them)
@@ -443,6 +495,7 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
     }
     for (long long f = fs; f < f1; ++f) {
         const bool emit = f >= f0;
+        fast_tw_touch<LOG2M>(tw);
         if (!(VEC2 && VOC_WS_PREFETCH) && f > fs) load_window(opaque_int(tid));  // predicated loads: not worth the registers of a prefetch
         wave_prio<VOC_PRIO_ANA_T, LOG2M>();
         C2 v[8];
@@ -454,7 +507,8 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
         dft<8>(v);
         // The last pass leaves element tid + n T of the spectrum with thread tid, and the thread's four bin
         // pairs are (tid + m T, M - tid - m T): the first of each pair is already here (n = 0..3), the second
-        // is the n = 7 - m of thread T - tid.  So only the upper four results go through LDS.
+        // is the n = 7 - m of thread T - tid.  So only the upper four results go through LDS (and the first,
+        // because thread 0's first pair is special).
         constexpr bool KEEP = VOC_LAST_IN_REGS != 0;
         fft_after_first<LOG2M, KEEP>(lds, tw, tid, v, [&]() {
             if (f + 1 < f1) {  // the pairs of the next frame that are not already in registers, and the window again
@@ -485,7 +539,7 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
             C2 *zw = lds + lds_sw(lt);
 #pragma unroll
             for (int n = 4; n < 8; ++n) zw[n * T] = v[nat_idx<LOG2M>(n)];
-            if (tid == 0) lds[0] = v[nat_idx<LOG2M>(0)];  // Z[0]: the DC / Nyquist pair, read by two other threads
+            zw[0] = v[nat_idx<LOG2M>(0)];  // thread 0's first pair is the self-paired bin M/2 (its own element 4 T), and Z[0] is read by two other threads
             __syncthreads();
         }
         // byte offsets of the pair's bins in an STFT row and in the phase array: slot 0 has its own, slots
@@ -501,12 +555,7 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
             const int ipe = m == 0 ? 0 : (m - 2) * T * SZ, iq = -ipe;
             C2 P, Q, w;
             if (m == 0) {
-                if constexpr (KEEP) {  // thread 0's self-paired bin M/2 is its own element 4 T
-                    const C2 va = v[nat_idx<LOG2M>(0)], vb = v[nat_idx<LOG2M>(4)];
-                    P = mk2(self0 ? vb.x : va.x, self0 ? vb.y : va.y);
-                } else {
-                    P = lds[lds_sw(pe)];
-                }
+                P = lds[lds_sw(pe)];
                 Q = lds[lds_sw(q)];
                 w = split_tw(tw.s, 0, self0);
             } else {
@@ -517,10 +566,18 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
             }
             C2 Xa, Xb;
             split_pair_x2(P, Q, w, Xa, Xb);
-            const R pa = at_bytes(php, ope, ipe), pb = at_bytes(php, oq, iq);
+            R pa, pb;
+            if constexpr (PAIRS) {
+                const C2 pp = at_bytes(php2, (unsigned)lt * (unsigned)sizeof(C2), m * T * (int)sizeof(C2));
+                pa = pp.x;
+                pb = pp.y;
+            } else {
+                pa = at_bytes(php, ope, ipe);
+                pb = at_bytes(php, oq, iq);
+            }
             R ma, mb, pha, phb;
-            hs_polar(Xa.x, Xa.y, ma, pha);
-            hs_polar(Xb.x, Xb.y, mb, phb);
+            hs_polar<VOC_POLAR_LEAN != 0>(Xa.x, Xa.y, ma, pha);
+            hs_polar<VOC_POLAR_LEAN != 0>(Xb.x, Xb.y, mb, phb);
             if (emit) {
                 at_bytes(mrow, ope, ipe) = ma * half_vol;
                 at_bytes(mrow, oq, iq) = mb * half_vol;
@@ -532,8 +589,12 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
                     at_bytes(irow, oq, iq) = phase_inc(p, q, phb - pb);
                 }
             }
-            at_bytes(php, ope, ipe) = pha;
-            at_bytes(php, oq, iq) = phb;
+            if constexpr (PAIRS) {
+                at_bytes(php2, (unsigned)lt * (unsigned)sizeof(C2), m * T * (int)sizeof(C2)) = mk2(pha, phb);
+            } else {
+                at_bytes(php, ope, ipe) = pha;
+                at_bytes(php, oq, iq) = phb;
+            }
             sched_fence();
         }
         // DC and Nyquist bins are real: phase 0 or pi, magnitude |x|.  Two different waves take one
@@ -544,11 +605,12 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
             const R xr = dc ? z0.x + z0.y : z0.x - z0.y;
             const int kb = dc ? 0 : M;
             const R phr = xr < (R)0 ? (R)kPi : (R)0;
+            R *pk = PAIRS ? php + 8 * T + (dc ? 0 : 1) : php + kb;
             if (emit) {
                 mrow[kb] = fabs(xr) * a.vol;
-                irow[kb] = SLIDE > 0 ? phase_inc_pow2(p, kb, phr - php[kb]) : phase_inc(p, kb, phr - php[kb]);
+                irow[kb] = SLIDE > 0 ? phase_inc_pow2(p, kb, phr - *pk) : phase_inc(p, kb, phr - *pk);
             }
-            php[kb] = phr;
+            *pk = phr;
         }
         // slide the sample window by one hop
 #pragma unroll
@@ -561,7 +623,21 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
     if (f1 == a.F && f1 > f0) {
         __syncthreads();
         R *po = a.phase_out + c * p.K;
-        for (int k = tid; k < p.K; k += T) po[k] = php[k];
+        if constexpr (PAIRS) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int pe = (m == 0 && tid == 0) ? M / 2 : tid + m * T;
+                const C2 pp = php2[tid + m * T];
+                po[pe] = pp.x;
+                po[M - pe] = pp.y;  // (thread 0, m = 0: the same bin and the same value twice)
+            }
+            if (tid == 0) {
+                po[0] = php2[4 * T].x;
+                po[M] = php2[4 * T].y;
+            }
+        } else {
+            for (int k = tid; k < p.K; k += T) po[k] = php[k];
+        }
     }
 }
 
@@ -671,6 +747,7 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
     for (long long f = fs; f < f1; ++f) {
         const long long row = c * a.F + f;
         const int lt = opaque_int(tid);  // keeps this frame's index arithmetic inside the loop
+        fast_tw_touch<LOG2M>(tw);
         wave_prio<VOC_PRIO_SYN_B, LOG2M>();
         if (!ROW_PF) load_row(f, lt);
         // m is a constant in every copy of the unrolled loop: the self-paired bin exists in the first
@@ -741,9 +818,21 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
             load8<LOG2M>(lds, lt, v);
         }
         dft<8>(v);
+        // window values of the overlap-add: uniform bases T pairs apart plus one lane offset.  Requested
+        // before the last pass (they come from L2: asked for only where they are used, their latency is
+        // exposed in the part of the frame that runs at the highest priority).
+        constexpr int WIN_EARLY = (OLA && KEEP_OUT) ? VOC_SYN_WIN_EARLY : 0;
+        C2 wv[NP];
+        const unsigned lane16 = (unsigned)lt * (unsigned)sizeof(C2);
+        auto load_win = [&](int j0, int j1) {
+#pragma unroll
+            for (int j = j0; j < j1; ++j) wv[j] = at_bytes(reinterpret_cast<const C2 *>(VOC_SYN_WIN_SCALED ? p.window_n : p.window) + j * T, lane16, 0);
+        };
         fft_after_first<LOG2M, KEEP_OUT>(lds, tw, lt, v, [&]() {
             if (ROW_PF && f + 1 < f1) load_row(f + 1, lt);
-        }, TW_LDS ? twl : nullptr);
+        }, TW_LDS ? twl : nullptr, [&]() {
+            load_win(NP - WIN_EARLY, NP);
+        });
         // lds[pad(m)] = swapped z[m]: v[2m] = z.y / N, v[2m+1] = z.x / N.  frame[i] = w[i] * v[(i + off + N/2) mod N]
         const bool emit = f >= f0;
         wave_prio<VOC_PRIO_SYN_O, LOG2M>();
@@ -751,11 +840,9 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
             // W == N (off = 0): window samples 2i, 2i+1 pair with complex element (i + M/2) mod M
             // element lt + e with e a multiple of T (of 64) sits at lds_sw(lt) + e: one LDS base plus
             // immediates; window and output rows: uniform bases T pairs apart plus one lane offset
-            C2 wv[NP], zv[NP];
-            const unsigned lane16 = (unsigned)lt * (unsigned)sizeof(C2);
+            C2 zv[NP];
             const C2 *zb = lds + lds_sw(lt);
-#pragma unroll
-            for (int j = 0; j < NP; ++j) wv[j] = at_bytes(reinterpret_cast<const C2 *>(p.window) + j * T, lane16, 0);
+            load_win(0, NP - WIN_EARLY);
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 const int e = (j * T + M / 2) & (M - 1);
@@ -766,9 +853,14 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 const C2 old = j < NK ? tail[j] : mk2((R)0, (R)0);
-                cur[j].x = old.x + wv[j].x * (zv[j].y * p.inv_n);
-                cur[j].y = old.y + wv[j].y * (zv[j].x * p.inv_n);
+                // w (z / N) and (w / N) z round alike: 1/N is a power of two (a window value below 2^-1010 aside)
+                cur[j].x = old.x + (VOC_SYN_WIN_SCALED ? wv[j].x * zv[j].y : wv[j].x * (zv[j].y * p.inv_n));
+                cur[j].y = old.y + (VOC_SYN_WIN_SCALED ? wv[j].y * zv[j].x : wv[j].y * (zv[j].x * p.inv_n));
             }
+            // (without this the compiler moves the loads and sums of the emitted pairs into the branch
+            //  below, one after the other behind the rest: two more round trips to L2 per frame)
+#pragma unroll
+            for (int j = 0; j < NHP; ++j) opaque(cur[j]);
             if (emit) {
                 C2 *yc = reinterpret_cast<C2 *>(a.out + c * a.out_stride + f * p.H);
 #pragma unroll

@@ -1198,10 +1198,15 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
             twS[k] = make_double2((double)cosl(ang), (double)-sinl(ang));
         }
         twS[c->M / 2] = make_double2(0.0, -1.0);  // exp(-i pi/2) exactly
-        HIPCHK(hipMalloc((void **)&c->d_window, sizeof(double) * (size_t)W));
+        // the window, then the window times 1/N: with N a power of two that product is exact, and the
+        // overlap-add of the specialised synthesis kernel multiplies by it instead of scaling every sample
+        std::vector<double> win2(window, window + W);
+        win2.resize(2 * (size_t)W);
+        for (int i = 0; i < W; ++i) win2[(size_t)W + i] = window[i] * (1.0 / (double)N);
+        HIPCHK(hipMalloc((void **)&c->d_window, sizeof(double) * win2.size()));
         HIPCHK(hipMalloc((void **)&c->d_twP, sizeof(double2) * twP.size()));
         HIPCHK(hipMalloc((void **)&c->d_twS, sizeof(double2) * twS.size()));
-        HIPCHK(hipMemcpy(c->d_window, window, sizeof(double) * (size_t)W, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_window, win2.data(), sizeof(double) * win2.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->d_twP, twP.data(), sizeof(double2) * twP.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->d_twS, twS.data(), sizeof(double2) * twS.size(), hipMemcpyHostToDevice));
 
@@ -1216,6 +1221,7 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
         p.inv_n = 1.0 / (double)N;
         p.omega1 = (p.hop_pow2 && !chirp) ? (voc::kTwoPi * (double)H) / (double)N : 0.0;  // exact scalings of 2 pi
         p.window = c->d_window;
+        p.window_n = c->d_window + W;
         p.twP = c->d_twP;
         p.twS = c->d_twS;
         if (chirp) {
@@ -1277,6 +1283,8 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
         if (precision == VOC_PRECISION_F32) {
             // the same tables rounded once to float (twiddles from the long double values, not from the doubles)
             std::vector<float> wf(window, window + W);
+            wf.resize(2 * (size_t)W);
+            for (int i = 0; i < W; ++i) wf[(size_t)W + i] = wf[i] * (1.0f / (float)N);
             std::vector<float2> tpf(twP.size()), tsf(twS.size());
             for (int ns = 1; ns < c->M;) {
                 const int rad = (c->M / ns) >= 8 ? 8 : (c->M / ns);
@@ -1293,10 +1301,10 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
                 tsf[k] = make_float2((float)cosl(ang), (float)-sinl(ang));
             }
             tsf[c->M / 2] = make_float2(0.0f, -1.0f);
-            HIPCHK(hipMalloc((void **)&c->d_window_f, sizeof(float) * (size_t)W));
+            HIPCHK(hipMalloc((void **)&c->d_window_f, sizeof(float) * wf.size()));
             HIPCHK(hipMalloc((void **)&c->d_twP_f, sizeof(float2) * tpf.size()));
             HIPCHK(hipMalloc((void **)&c->d_twS_f, sizeof(float2) * tsf.size()));
-            HIPCHK(hipMemcpy(c->d_window_f, wf.data(), sizeof(float) * (size_t)W, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(c->d_window_f, wf.data(), sizeof(float) * wf.size(), hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(c->d_twP_f, tpf.data(), sizeof(float2) * tpf.size(), hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(c->d_twS_f, tsf.data(), sizeof(float2) * tsf.size(), hipMemcpyHostToDevice));
             voc::ParamsT<float> &q = c->params_f;
@@ -1306,6 +1314,7 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
             q.inv_hop = 1.0f / (float)H;
             q.inv_n = 1.0f / (float)N;
             q.window = c->d_window_f;
+            q.window_n = c->d_window_f + W;
             q.twP = c->d_twP_f;
             q.twS = c->d_twS_f;
         }
