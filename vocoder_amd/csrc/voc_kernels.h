@@ -362,7 +362,7 @@ VOC_DEV void hs_polar(double x, double y, double &mag, double &ph)
     const int e = frexp_exponent(fmax(ax, ay));
     const double sx = ldexp(ax, -e), sy = ldexp(ay, -e);
     const double a = sx * sx, b = sy * sy;
-    const double r = sqrt_scaled<LEAN>(a + b);  // in [0.5, 1.42), or 0
+    const double r = sqrt_scaled<LEAN>(LEAN ? fma(sy, sy, a) : a + b);  // in [0.5, 1.42), or 0
     mag = ldexp(r, e);
     const double d0 = r + sx;             // in [0.5, 2.42), or 0
     const double f = (sy > 0.41421356237309503 * d0) ? 1.0 : 0.0;

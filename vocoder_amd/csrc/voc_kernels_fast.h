@@ -20,6 +20,14 @@
 
 #include "voc_kernels.h"
 
+#ifndef VOC_FMA_BF
+#define VOC_FMA_BF 1  // twiddle products folded into the first butterfly stage: a = t + w u as two fused multiply-adds per component, b = 2 t - a
+#endif
+
+#ifndef VOC_FMA_MORE
+#define VOC_FMA_MORE 0  // (measured: synthesis -0.6 %, analysis unchanged; left off) products that feed one sum directly (window times sample, modulus times cosine / sine, window times output sample, the half-turn factors inside the radix-8 butterfly) are fused into that sum
+#endif
+
 #ifndef VOC_WS_PREFETCH
 #define VOC_WS_PREFETCH 0  // fetch the window with the next frame's samples (aligned case)
 #endif
@@ -60,6 +68,7 @@
 #define VOC_POLAR_LEAN 1  // analysis: the shorter polar conversion (see div_pos in voc_kernels.h)
 #endif
 
+
 #ifndef VOC_LAST_IN_REGS
 #define VOC_LAST_IN_REGS 1  // the transform's last results (analysis, synthesis) and first inputs (synthesis) stay in registers where the same thread uses them
 #endif
@@ -96,11 +105,18 @@ struct FastCfg {
 template <class C2>
 VOC_DEV void split_pair_x2(C2 P, C2 Q, C2 tw, C2 &Xa, C2 &Xb)
 {
+    using R = decltype(P.x);
     const C2 E = mk2(P.x + Q.x, P.y - Q.y);
     const C2 O = mk2(P.y + Q.y, Q.x - P.x);
+#if VOC_FMA_BF
+    // E + W O as fused multiply-adds, E - W O as 2 E - (E + W O): ten instructions instead of twelve
+    Xa = mk2(fma(tw.x, O.x, fma(-tw.y, O.y, E.x)), fma(tw.x, O.y, fma(tw.y, O.x, E.y)));
+    Xb = mk2(fma((R)2, E.x, -Xa.x), fma((R)-2, E.y, Xa.y));
+#else
     const C2 U = cmul(tw, O);
     Xa = cadd(E, U);
     Xb = cconj(csub(E, U));
+#endif
 }
 
 // inverse of split_pair, without the factor 1/2 (folded into the final 1/N):
@@ -109,11 +125,29 @@ VOC_DEV void split_pair_x2(C2 P, C2 Q, C2 tw, C2 &Xa, C2 &Xb)
 template <class C2>
 VOC_DEV void merge_pair(C2 A, C2 B, C2 tw, C2 &Za, C2 &Zb)
 {
+    using R = decltype(A.x);
     const C2 S = mk2(A.x + B.x, A.y - B.y);
     const C2 D = mk2(A.x - B.x, A.y + B.y);
+#if VOC_FMA_BF
+    // with Tw = D conj(tw): Za = (S.y + Tw.x, S.x - Tw.y) as fused multiply-adds, Zb = (Za.x - 2 S.y, 2 S.x - Za.y)
+    Za = mk2(fma(D.x, tw.x, fma(D.y, tw.y, S.y)), fma(D.x, tw.y, fma(-D.y, tw.x, S.x)));
+    Zb = mk2(fma((R)-2, S.y, Za.x), fma((R)2, S.x, -Za.y));
+#else
     const C2 Tw = cmul_conj(D, tw);
     Za = mk2(S.y + Tw.x, S.x - Tw.y);
     Zb = mk2(Tw.x - S.y, S.x + Tw.y);
+#endif
+}
+
+// merge_pair for A = mag (c + i s) given in parts: the products with the modulus are fused into the sums
+// with B (two instructions less than forming A first)
+template <class C2, class R>
+VOC_DEV void merge_pair_polar(R mag, R c, R s, C2 B, C2 tw, C2 &Za, C2 &Zb)
+{
+    const C2 S = mk2(fma(mag, c, B.x), fma(mag, s, -B.y));
+    const C2 D = mk2(fma(mag, c, -B.x), fma(mag, s, B.y));
+    Za = mk2(fma(D.x, tw.x, fma(D.y, tw.y, S.y)), fma(D.x, tw.y, fma(-D.y, tw.x, S.x)));
+    Zb = mk2(fma((R)-2, S.y, Za.x), fma((R)2, S.x, -Za.y));
 }
 
 // Where complex element i of the transform lives in LDS: i with its low three bits XORed by the next
@@ -202,6 +236,105 @@ VOC_DEV R &at_bytes(R *base, unsigned byte_off, int imm)
 
 template <class C2>
 VOC_DEV C2 csqr(C2 a) { return mk2(fma(a.x, a.x, -(a.y * a.y)), (a.x + a.x) * a.y); }
+
+// (a, b) <- (t + w u, t - w u) without forming w u: the sum as two fused multiply-adds per component, the
+// difference as 2 t - sum (one each).  Six instructions where the product and a plain butterfly take
+// eight; the difference carries the sum's rounding error, i.e. an error relative to the larger of the
+// two results -- the order every butterfly's inputs already have.
+template <class C2>
+VOC_DEV void bf2_tw(C2 t, C2 u, C2 w, C2 &a, C2 &b)
+{
+    using R = decltype(t.x);
+    a = mk2(fma(w.x, u.x, fma(-w.y, u.y, t.x)), fma(w.x, u.y, fma(w.y, u.x, t.y)));
+    b = mk2(fma((R)2, t.x, -a.x), fma((R)2, t.y, -a.y));
+}
+
+// the radix-8 butterfly after its first stage (v[j] +- v[j + 4] done): as dft_n for eight points, with the
+// factor sqrt(1/2) of the eighth-turn twiddles fused into the butterfly that follows them
+template <class C2>
+VOC_DEV void dft8_rest(C2 (&v)[8])
+{
+    using R = decltype(v[0].x);
+    const R kh = (R)kSqrtHalf;
+    v[6] = mul_mi(v[6]);
+    bf2(v[0], v[2]);
+    bf2(v[1], v[3]);
+    v[3] = mul_mi(v[3]);
+    bf2(v[4], v[6]);
+#if VOC_FMA_MORE
+    {   // v5 <- W8 v5 = kh p5, v7 <- W8^3 v7 = kh p7, then (v5, v7) <- (v5 + v7, v5 - v7)
+        const C2 p5 = mk2(v[5].x + v[5].y, v[5].y - v[5].x);
+        const C2 p7 = mk2(v[7].y - v[7].x, -(v[7].x + v[7].y));
+        const C2 t7 = mk2(p7.x * kh, p7.y * kh);
+        v[5] = mk2(fma(kh, p5.x, t7.x), fma(kh, p5.y, t7.y));
+        v[7] = mk2(fma(kh, p5.x, -t7.x), fma(kh, p5.y, -t7.y));
+    }
+#else
+    v[5] = mk2((v[5].x + v[5].y) * kh, (v[5].y - v[5].x) * kh);
+    v[7] = mk2((v[7].y - v[7].x) * kh, -((v[7].x + v[7].y) * kh));
+    bf2(v[5], v[7]);
+#endif
+    v[7] = mul_mi(v[7]);
+    bf2(v[0], v[1]);
+    bf2(v[2], v[3]);
+    bf2(v[4], v[5]);
+    bf2(v[6], v[7]);
+    C2 t;
+    t = v[1]; v[1] = v[4]; v[4] = t;
+    t = v[3]; v[3] = v[6]; v[6] = t;
+}
+
+// radix-8 butterfly of v[j] w^j, j = 0..7 (w^0 = 1), natural order in and out
+template <class C2>
+VOC_DEV void dft8_tw(C2 (&v)[8], C2 w1)
+{
+    using R = decltype(w1.x);
+    const R kh = (R)kSqrtHalf;
+    const C2 w2 = csqr(w1);
+    const C2 w3 = cmul(w2, w1);
+    const C2 w4 = csqr(w2);
+    C2 a, b;
+    bf2_tw(v[0], v[4], w4, a, b);
+    v[0] = a;
+    v[4] = b;
+    bf2_tw(cmul(v[1], w1), v[5], cmul(w4, w1), a, b);
+    v[1] = a;
+    v[5] = b;
+    bf2_tw(cmul(v[2], w2), v[6], csqr(w3), a, b);
+    v[2] = a;
+    v[6] = b;
+    bf2_tw(cmul(v[3], w3), v[7], cmul(w4, w3), a, b);
+    v[3] = a;
+    v[7] = b;
+    dft8_rest(v);
+}
+
+template <class C2>
+VOC_DEV void dft4_tw(C2 (&v)[4], C2 w1)
+{
+    const C2 w2 = csqr(w1);
+    C2 a, b;
+    bf2_tw(v[0], v[2], w2, a, b);
+    v[0] = a;
+    v[2] = b;
+    bf2_tw(cmul(v[1], w1), v[3], cmul(w2, w1), a, b);
+    v[1] = a;
+    v[3] = mul_mi(b);
+    bf2(v[0], v[1]);
+    bf2(v[2], v[3]);
+    const C2 t = v[1];
+    v[1] = v[2];
+    v[2] = t;
+}
+
+template <class C2>
+VOC_DEV void dft2_tw(C2 (&v)[2], C2 w1)
+{
+    C2 a, b;
+    bf2_tw(v[0], v[1], w1, a, b);
+    v[0] = a;
+    v[1] = b;
+}
 
 template <int LOG2M, class C2>
 struct FastTw {
@@ -320,6 +453,14 @@ VOC_DEV void pass4_compute(const C2 *lds, int tid, const FastTw<LOG2M, C2> &t, C
             for (int j = 0; j < R4; ++j) w[j] = src[j * NBF];
             C2 pw = t.d[q];
             if (!VOC_TW_OPAQUE_TOP) opaque(pw);
+            if constexpr (VOC_FMA_BF != 0) {
+                if constexpr (R4 == 8) dft8_tw(w, pw);
+                else if constexpr (R4 == 4) dft4_tw(w, pw);
+                else dft2_tw(w, pw);
+#pragma unroll
+                for (int j = 0; j < R4; ++j) v[q * R4 + j] = w[j];
+                continue;
+            }
             w[1] = cmul(w[1], pw);
             if constexpr (R4 >= 4) {
                 const C2 w2 = csqr(pw);
@@ -386,17 +527,29 @@ VOC_DEV void fft_after_first(C2 *lds, const FastTw<LOG2M, C2> &t, int tid, C2 (&
     store8<LOG2M, 1>(lds, tid, v);
     __syncthreads();
     load8<LOG2M>(lds, tid, v);
-    if (twl) twiddle8_tab(v, twl + (tid & 7), 8);
-    else twiddle8(v, t.b);
-    dft<8>(v);
+    if (twl) {
+        twiddle8_tab(v, twl + (tid & 7), 8);
+        dft<8>(v);
+    } else if (VOC_FMA_BF) {
+        dft8_tw(v, t.b);
+    } else {
+        twiddle8(v, t.b);
+        dft<8>(v);
+    }
     __syncthreads();
     store8<LOG2M, 8>(lds, tid, v);
     __syncthreads();
     if (R4 == 1) early();
     load8<LOG2M>(lds, tid, v);
-    if (twl) twiddle8_tab(v, twl + 56 + (tid & 63), 64);
-    else twiddle8(v, t.c);
-    dft<8>(v);
+    if (twl) {
+        twiddle8_tab(v, twl + 56 + (tid & 63), 64);
+        dft<8>(v);
+    } else if (VOC_FMA_BF) {
+        dft8_tw(v, t.c);
+    } else {
+        twiddle8(v, t.c);
+        dft<8>(v);
+    }
     if (R4 == 1) prefetch();
     if (R4 == 1 && KEEP_LAST) return;
     __syncthreads();
@@ -499,12 +652,25 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
         if (!(VEC2 && VOC_WS_PREFETCH) && f > fs) load_window(opaque_int(tid));  // predicated loads: not worth the registers of a prefetch
         wave_prio<VOC_PRIO_ANA_T, LOG2M>();
         C2 v[8];
+        if constexpr (VOC_FMA_MORE != 0) {
+            // first stage of the radix-8 butterfly on the windowed samples: the product of the upper input is
+            // fused into the sum and the difference
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int u = (j + 4) & 7;
-            v[j] = mk2(ws[u].x * xs[u].x, ws[u].y * xs[u].y);
+            for (int j = 0; j < 4; ++j) {
+                const int u = (j + 4) & 7, u4 = j;  // inputs j and j + 4 are slots (j + 4) mod 8 and j
+                const C2 pj = mk2(ws[u].x * xs[u].x, ws[u].y * xs[u].y);
+                v[j] = mk2(fma(ws[u4].x, xs[u4].x, pj.x), fma(ws[u4].y, xs[u4].y, pj.y));
+                v[j + 4] = mk2(fma(-ws[u4].x, xs[u4].x, pj.x), fma(-ws[u4].y, xs[u4].y, pj.y));
+            }
+            dft8_rest(v);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int u = (j + 4) & 7;
+                v[j] = mk2(ws[u].x * xs[u].x, ws[u].y * xs[u].y);
+            }
+            dft<8>(v);
         }
-        dft<8>(v);
         // The last pass leaves element tid + n T of the spectrum with thread tid, and the thread's four bin
         // pairs are (tid + m T, M - tid - m T): the first of each pair is already here (n = 0..3), the second
         // is the n = 7 - m of thread T - tid.  So only the upper four results go through LDS (and the first,
@@ -766,7 +932,14 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
             const unsigned pe = self ? M / 2 : (unsigned)(lt + m * T);
             const unsigned q = M - pe;
             C2 A, B;
-            if constexpr (PHASE_REGS) {
+            constexpr bool POLAR_FUSED = VOC_FMA_MORE != 0 && VOC_FMA_BF != 0 && PHASE_REGS;
+            R sa = (R)0, ca = (R)0;
+            if constexpr (POLAR_FUSED) {
+                phr[2 * m] = phase_step(phr[2 * m], ic[2 * m] * p.hop_d);
+                fast_sincos<LEAN>(phr[2 * m], &sa, &ca);
+                A = mk2((R)0, (R)0);
+                B = synthesize_bin<R, LEAN>(p, mg[2 * m + 1], ic[2 * m + 1], phr[2 * m + 1]);
+            } else if constexpr (PHASE_REGS) {
                 A = synthesize_bin<R, LEAN>(p, mg[2 * m], ic[2 * m], phr[2 * m]);
                 B = synthesize_bin<R, LEAN>(p, mg[2 * m + 1], ic[2 * m + 1], phr[2 * m + 1]);
             } else {
@@ -777,7 +950,8 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
                 php[q] = pb;
             }
             C2 Za, Zb;
-            merge_pair(A, B, split_tw(tw.s, m, self), Za, Zb);
+            if constexpr (POLAR_FUSED) merge_pair_polar(mg[2 * m], ca, sa, B, split_tw(tw.s, m, self), Za, Zb);
+            else merge_pair(A, B, split_tw(tw.s, m, self), Za, Zb);
             za[m] = Za;
             if (m == 0) {
                 if constexpr (!KEEP_IN) lds[lds_sw(pe)] = Za;
@@ -817,7 +991,9 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
         } else {
             load8<LOG2M>(lds, lt, v);
         }
-        dft<8>(v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf2(v[j], v[j + 4]);
+        dft8_rest(v);
         // window values of the overlap-add: uniform bases T pairs apart plus one lane offset.  Requested
         // before the last pass (they come from L2: asked for only where they are used, their latency is
         // exposed in the part of the frame that runs at the highest priority).
@@ -854,8 +1030,13 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
             for (int j = 0; j < NP; ++j) {
                 const C2 old = j < NK ? tail[j] : mk2((R)0, (R)0);
                 // w (z / N) and (w / N) z round alike: 1/N is a power of two (a window value below 2^-1010 aside)
-                cur[j].x = old.x + (VOC_SYN_WIN_SCALED ? wv[j].x * zv[j].y : wv[j].x * (zv[j].y * p.inv_n));
-                cur[j].y = old.y + (VOC_SYN_WIN_SCALED ? wv[j].y * zv[j].x : wv[j].y * (zv[j].x * p.inv_n));
+                if constexpr (VOC_FMA_MORE != 0 && VOC_SYN_WIN_SCALED != 0) {
+                    cur[j].x = fma(wv[j].x, zv[j].y, old.x);
+                    cur[j].y = fma(wv[j].y, zv[j].x, old.y);
+                } else {
+                    cur[j].x = old.x + (VOC_SYN_WIN_SCALED ? wv[j].x * zv[j].y : wv[j].x * (zv[j].y * p.inv_n));
+                    cur[j].y = old.y + (VOC_SYN_WIN_SCALED ? wv[j].y * zv[j].x : wv[j].y * (zv[j].x * p.inv_n));
+                }
             }
             // (without this the compiler moves the loads and sums of the emitted pairs into the branch
             //  below, one after the other behind the rest: two more round trips to L2 per frame)
