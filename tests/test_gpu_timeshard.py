@@ -148,3 +148,45 @@ def test_one_rank_in_pieces_equals_whole_signal(gpu_lib, orc, chain):
     if chain == "identity":
         ref = orc.roundtrip(n, hop, win, x[1], hop, np.zeros(par.K), np.zeros(par.K))
         assert np.linalg.norm(y[1].cpu().numpy() - ref["y"]) / np.linalg.norm(ref["y"]) <= TOL_L2
+
+
+@pytest.mark.parametrize("n,hop", [(1024, 256), (2048, 512), (4096, 1024), (8192, 2048)])
+def test_fused_analysis_accuracy_is_as_stated(gpu_lib, orc, n, hop):
+    """The fused analysis kernels use the shorter polar conversion (no residual correction of quotient and square
+    root, degree-8 arctangent).  Its stated accuracy -- magnitudes within 1e-13 of the frame maximum, raw phases
+    within 1e-12 rad, per-hop phase advance within 1e-11 rad (it is formed at a few thousand radians, where
+    one ulp is 5e-13) -- is four to five orders inside the 1e-9 bars of the path, and is held here against the
+    CPU restatement of Vocoder.hs:158-173,217-218.  Phases are compared on bins of at least a hundredth of the
+    frame's maximum: below that the two transforms' own rounding (1e-16 of the maximum) already moves a phase by
+    more than the bar."""
+    import ctypes as C
+    import torch
+    from vocoder_amd import vocoder as V
+    win = _hann(n)
+    par = V.VocoderParams(n, hop, win, lib=gpu_lib)
+    c, frames = 2, 9
+    length = n + hop * (frames - 1)
+    xs = _signal(c, length)
+    x = torch.from_numpy(xs).cuda()
+    ldk = (par.K + 1) & ~1
+    mag = torch.empty((c, frames, ldk), dtype=torch.float64, device="cuda")
+    inc = torch.empty_like(mag)
+    rng = np.random.default_rng(3)
+    ph0 = rng.uniform(-3, 3, (c, par.K))
+    aph = torch.from_numpy(ph0.copy()).cuda()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    par._call("voc_analysis_signal_dev", p(x), x.stride(0), frames, c, p(aph), p(mag), p(inc), ldk, 0, st)
+    torch.cuda.synchronize()
+    mag, inc, aph = mag.cpu().numpy()[:, :, :par.K], inc.cpu().numpy()[:, :, :par.K], aph.cpu().numpy()
+    for ch in range(c):
+        fr = np.stack([xs[ch, j * hop: j * hop + n] for j in range(frames)])
+        pho, mago, inco = orc.analysis_stage(n, hop, win, ph0[ch], fr)
+        top = mago.max(axis=-1, keepdims=True)
+        assert (np.abs(mag[ch] - mago) <= 1e-13 * top).all()
+        big = mago >= 1e-2 * top
+        d = np.abs(inc[ch] * hop - inco * hop) % (2 * np.pi)
+        assert np.minimum(d, 2 * np.pi - d)[big].max() <= 1e-11
+        d = np.abs(aph[ch] - pho) % (2 * np.pi)
+        assert np.minimum(d, 2 * np.pi - d)[big[-1]].max() <= 1e-12
+    par.close()
