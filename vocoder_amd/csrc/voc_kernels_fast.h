@@ -80,6 +80,10 @@
 #define VOC_PRAGMA_(x) _Pragma(#x)
 #define VOC_UNROLL(n) VOC_PRAGMA_(unroll n)
 
+#ifndef VOC_SYN_FAT
+#define VOC_SYN_FAT 1  // synthesis with overlap-add, N >= 2048, double: budgeted for two waves per SIMD (256 registers): the next STFT row is requested a frame ahead and the window stays in registers
+#endif
+
 #ifndef VOC_FAST_WAVES
 #define VOC_FAST_WAVES 3  // waves per SIMD the fast kernels are register-budgeted for
 #endif
@@ -807,6 +811,11 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
     }
 }
 
+// Whether the synthesis kernel is built for two waves per SIMD (see VOC_SYN_FAT): the host's count of resident
+// workgroups (synthesis_slots) follows the same rule.
+template <int LOG2M, bool OLA, class R>
+constexpr bool syn_fat() { return VOC_SYN_FAT != 0 && LOG2M >= 10 && OLA && sizeof(R) == 8; }
+
 // OLA = false: frames out ([C][F][W]).
 // OLA = true: overlap-add in registers.  Requires W == N and H = NHP * 2T: thread t owns the sample
 // PAIRS (2(t + jT), 2(t + jT) + 1), j = 0..7, of the N-sample window -- one complex LDS element,
@@ -815,7 +824,7 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
 // MAPPED: rows are looked up through a.mag_rows / a.inc_rows (a build of its own: the lookups cost
 // the unmapped path 1 % when they are decided at run time).
 template <int LOG2M, bool OLA, int NHP, class R = double, bool MAPPED = false>
-__global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_fast_kernel(ParamsT<R> p, SynArgsT<R> a)
+__global__ void __launch_bounds__(FastCfg<LOG2M>::T, (syn_fat<LOG2M, OLA, R>() ? 2 : VOC_FAST_WAVES)) synthesis_fast_kernel(ParamsT<R> p, SynArgsT<R> a)
 {
     using C2 = cplx<R>;
     constexpr int M = FastCfg<LOG2M>::M, T = FastCfg<LOG2M>::T, N = 2 * M;
@@ -839,11 +848,12 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
     // registers staying live across the transform.  Measured (MI355X, fp64): without it the kernel
     // needs 133 instead of 166 registers and runs 5-11 % faster at N >= 2048; the one-wave workgroups
     // of N = 1024 are 4 % faster with it.
-    constexpr bool ROW_PF = VOC_SYN_ROW_PREFETCH == 1 || (VOC_SYN_ROW_PREFETCH == 2 && LOG2M <= 9);
-    constexpr bool LEAN = !ROW_PF;  // the branch-free sine / cosine pays only with the registers the prefetch took
+    constexpr bool SFAT = syn_fat<LOG2M, OLA, R>();
+    constexpr bool ROW_PF = SFAT || VOC_SYN_ROW_PREFETCH == 1 || (VOC_SYN_ROW_PREFETCH == 2 && LOG2M <= 9);
+    constexpr bool LEAN = !ROW_PF || SFAT;  // the branch-free sine / cosine pays only with the registers the prefetch took
     // ... and so does keeping the accumulated phases of this thread's eight bins (and of DC / Nyquist
     // in thread 0) in registers instead of LDS: 4 % faster at N = 4096, 29 % slower at N = 1024.
-    constexpr bool PHASE_REGS = VOC_SYN_PHASE_REGS && !ROW_PF;
+    constexpr bool PHASE_REGS = VOC_SYN_PHASE_REGS && (!ROW_PF || SFAT);
     R phr[8] = {}, ph0 = (R)0, phm = (R)0;
     if constexpr (PHASE_REGS) {
         const R *pi = (tile == 0) ? a.phase_in + c * p.K : a.carry + ((c - a.unsplit) * a.tiles + tile) * p.K;
@@ -910,6 +920,11 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
     };
 
     if (ROW_PF) load_row(fs, opaque_int(tid));
+    C2 wres[NP];
+    if constexpr (SFAT) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) wres[j] = at_bytes(reinterpret_cast<const C2 *>(VOC_SYN_WIN_SCALED ? p.window_n : p.window) + j * T, (unsigned)tid * (unsigned)sizeof(C2), 0);
+    }
     for (long long f = fs; f < f1; ++f) {
         const long long row = c * a.F + f;
         const int lt = opaque_int(tid);  // keeps this frame's index arithmetic inside the loop
@@ -979,6 +994,7 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
             if constexpr (KEEP_IN) za[0] = z0;  // element 0; thread 0's slot 0 was bin M/2, which it reads back as element 4 T
             else lds[0] = z0;
         }
+        if (SFAT && f + 1 < f1) load_row(f + 1, lt);
         wave_prio<VOC_PRIO_SYN_T, LOG2M>();
         __syncthreads();
         C2 v[8];
@@ -1005,10 +1021,14 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
             for (int j = j0; j < j1; ++j) wv[j] = at_bytes(reinterpret_cast<const C2 *>(VOC_SYN_WIN_SCALED ? p.window_n : p.window) + j * T, lane16, 0);
         };
         fft_after_first<LOG2M, KEEP_OUT>(lds, tw, lt, v, [&]() {
-            if (ROW_PF && f + 1 < f1) load_row(f + 1, lt);
+            if (ROW_PF && !SFAT && f + 1 < f1) load_row(f + 1, lt);
         }, TW_LDS ? twl : nullptr, [&]() {
-            load_win(NP - WIN_EARLY, NP);
+            if constexpr (!SFAT) load_win(NP - WIN_EARLY, NP);
         });
+        if constexpr (SFAT) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) wv[j] = wres[j];
+        }
         // lds[pad(m)] = swapped z[m]: v[2m] = z.y / N, v[2m+1] = z.x / N.  frame[i] = w[i] * v[(i + off + N/2) mod N]
         const bool emit = f >= f0;
         wave_prio<VOC_PRIO_SYN_O, LOG2M>();
@@ -1018,7 +1038,7 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) synthesis_f
             // immediates; window and output rows: uniform bases T pairs apart plus one lane offset
             C2 zv[NP];
             const C2 *zb = lds + lds_sw(lt);
-            load_win(0, NP - WIN_EARLY);
+            if constexpr (!SFAT) load_win(0, NP - WIN_EARLY);
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 const int e = (j * T + M / 2) & (M - 1);

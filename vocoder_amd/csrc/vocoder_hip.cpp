@@ -924,7 +924,8 @@ long long synthesis_slots(const voc_ctx *c)
     const bool f32 = c->precision == VOC_PRECISION_F32;
     const long long t = c->M / 8;
     const long long lds = (long long)(c->M * 2 + ((c->K + 1) & ~1)) * (f32 ? 4 : 8);  // FastCfg::lds_bytes
-    long long by_lds = (long long)kLdsLimit / lds, by_regs = (f32 ? 16 : 12) * 64 / t;
+    const bool fat = VOC_SYN_FAT != 0 && c->log2m >= 10 && !f32;  // voc::syn_fat: two waves per SIMD instead of three
+    long long by_lds = (long long)kLdsLimit / lds, by_regs = (f32 ? 16 : (fat ? 8 : 12)) * 64 / t;
     long long per_cu = by_lds < by_regs ? by_lds : by_regs;
     if (per_cu < 1) per_cu = 1;
     return 256 * per_cu;
