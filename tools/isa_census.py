@@ -53,8 +53,8 @@ def main():
     blocks = re.split(r"(?=remark: [^\n]*Function Name:)", remarks)
     with open(os.path.join(out_dir, "r02_resource_usage.txt"), "w") as f:
         f.write("# hipcc -Rpass-analysis=kernel-resource-usage, gfx950, N = 4096 kernels of the metric configuration.\n"
-                "# LDS is sized at launch (dynamic): 53 408 B per workgroup in analysis (FFT area + previous phases),\n"
-                "# 36 896 B in synthesis; with 256 threads per workgroup both run 3 workgroups (12 waves) per CU.\n")
+                "# LDS is sized at launch (dynamic): 49 168 B per workgroup of 256 threads (FFT area + phase area).\n"
+                "# Analysis runs 3 workgroups (12 waves) per CU; synthesis is built for 2 waves per SIMD (2 workgroups per CU).\n")
         for b in blocks:
             if any(h in b for h in HOT):
                 for line in b.splitlines():
