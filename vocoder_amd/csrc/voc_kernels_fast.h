@@ -1,21 +1,26 @@
 // voc_kernels_fast.h -- the hot-path kernels for 1024 <= N <= 8192 (M = N/2 complex points,
 // T = M/8 threads per frame: 8 complex points and 4 (k, M-k) bin pairs per thread).
 //
-// Same arithmetic as the generic kernels in voc_kernels.h.  What differs is scheduling: a
-// workgroup's per-frame critical path is a chain of memory round trips (input samples, per-pass
-// twiddles, split twiddles, STFT rows) separated by barriers, and with three workgroups per CU
-// there are too few waves to hide them.  So every global load is issued one stage ahead of its
-// use, and always BEFORE the stores of the current stage (loads and stores retire in issue
-// order, so a load queued behind stores waits for them):
-//   - the next frame's samples / window (analysis) or STFT row (synthesis) are fetched while the
-//     current frame is still in its last FFT pass;
-//   - the twiddles of FFT pass p+1 are fetched before the barriers that end pass p;
-//   - the split twiddles exp(-2 pi i k / N) of a thread's four bin pairs are frame invariant and
-//     stay in registers for the life of the workgroup.
-// State carried from frame to frame (previous raw phase in analysis, accumulated phase in
-// synthesis) sits in an LDS array of K doubles that only the owning thread touches; the
-// overlap-add partial sums of the N-sample window sit in 16 registers per thread (sample i of
-// the window belongs to thread i mod T) and shift by H/T slots per frame.
+// Same arithmetic as the generic kernels in voc_kernels.h (the fused analysis uses the shorter polar
+// conversion, see div_pos there).  What differs is how the work is laid on the machine.  These kernels
+// are bound by instruction issue: a SIMD spends about four fifths of its cycles on fp64 vector
+// instructions and most of the rest on LDS instructions (a 16-byte LDS write keeps its SIMD from issuing
+// vector instructions for about as long as seven of them), so the design counts instructions:
+//   - nothing is loaded that can be formed: each thread keeps one twiddle base per pass and multiplies the
+//     powers out, and the products with them are folded into the butterflies (bf2_tw);
+//   - nothing goes through LDS that its own thread uses next: the last pass leaves element tid + n T with
+//     thread tid, which owns the bin pairs (tid + m T, M - tid - m T) and, in synthesis, the output samples
+//     of exactly those elements (nat_idx, KEEP_LAST) -- half of the spectrum of analysis, half of the
+//     first-pass input of synthesis and the whole input of the overlap-add never leave their registers;
+//   - every memory access is a uniform base, one 32-bit lane offset and an immediate (at_bytes);
+//   - the next frame's samples (analysis) are requested during the current frame's last pass, always BEFORE
+//     the stores of the current stage (loads and stores retire in issue order);
+//   - a wave's priority follows its progress through the frame (wave_prio).
+// State carried from frame to frame: the previous raw phases of analysis sit in LDS behind the transform
+// area, the two bins of a pair side by side; its samples slide through registers (slot u of a thread: the
+// pair at frame positions 2 tid + 2 u T).  Synthesis with overlap-add (N >= 2048, double) is built for two
+// waves per SIMD instead of three: its accumulated phases, its overlap-add partial sums (pair slots that
+// shift by H / 2T per frame), its window and the STFT row of the next frame all live in registers.
 #pragma once
 
 #include "voc_kernels.h"
