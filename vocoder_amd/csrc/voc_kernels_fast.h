@@ -297,8 +297,6 @@ VOC_DEV void dft8_rest(C2 (&v)[8])
 template <class C2>
 VOC_DEV void dft8_tw(C2 (&v)[8], C2 w1)
 {
-    using R = decltype(w1.x);
-    const R kh = (R)kSqrtHalf;
     const C2 w2 = csqr(w1);
     const C2 w3 = cmul(w2, w1);
     const C2 w4 = csqr(w2);
