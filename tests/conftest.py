@@ -31,6 +31,7 @@ def emu_lib():
     so = os.path.join(d, "libvocoder_emu.so")
     srcs = [os.path.join(d, "hip_emu.h"), os.path.join(ROOT, "vocoder_amd", "csrc", "voc_kernels.h"),
             os.path.join(ROOT, "vocoder_amd", "csrc", "vocoder_hip.cpp"), os.path.join(ROOT, "vocoder_amd", "csrc", "voc_kernels_fast.h"),
+            os.path.join(ROOT, "vocoder_amd", "csrc", "voc_kernels_fast16.h"),
             os.path.join(ROOT, "include", "vocoder_hip.h")]
     if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         try:

@@ -35,6 +35,16 @@ def test_roundtrip(emu_lib, orc, n, w, h, length, c, at, st, chunk):
     Hh.check_roundtrip(emu_lib, orc, n, w, h, length, c, np.random.default_rng(2), ana_tile=at, syn_tile=st, chunk=chunk)
 
 
+@pytest.mark.parametrize("ana16,syn16", [(1, 0), (1, 1)])
+@pytest.mark.parametrize("n,h,nf,c,at,st", [(4096, 1024, 9, 2, 0, 0), (4096, 1024, 14, 1, 4, 5), (4096, 256, 20, 1, 6, 8),
+                                            (4096, 2048, 7, 1, 3, 3), (8192, 2048, 6, 1, 0, 0), (8192, 1024, 9, 1, 4, 4)])
+def test_sixteen_points_per_thread(emu_lib, orc, monkeypatch, n, h, nf, c, at, st, ana16, syn16):
+    """Index logic of the kernels with sixteen points per thread (N = 4096 / 8192: radix 16 * 16 * 8 or 16)."""
+    monkeypatch.setenv("VOC_FAST16_ANA", str(ana16))
+    monkeypatch.setenv("VOC_FAST16_SYN", str(syn16))
+    Hh.check_roundtrip(emu_lib, orc, n, n, h, n + h * (nf - 1) + 6, c, np.random.default_rng(n + h), ana_tile=at, syn_tile=st)
+
+
 def test_steps_and_framing(emu_lib, orc):
     from vocoder_amd import vocoder as V, conduit as Cd
     rng = np.random.default_rng(3)

@@ -95,6 +95,24 @@
 
 namespace voc {
 
+// Diagnostic builds (-DVOC_STAMPS): every wave sums the shader-clock time it spends between the marks of the
+// frame loop and adds its sums to a device table the launcher prints.  A mark drains the wave's LDS and scalar
+// memory counters first (the clock is read through the scalar memory path), so the marked build is slower
+// than the product and shows where a frame's time goes, not how long a frame takes.
+#if defined(VOC_STAMPS) && !defined(VOC_EMU)
+constexpr int kStampSlots = 16;
+__device__ unsigned long long voc_stamps[2][kStampSlots + 1];
+#define VOC_STAMP_DECL unsigned st_acc[kStampSlots] = {}; unsigned long long st_prev = __builtin_readcyclecounter(); unsigned st_frames = 0
+#define VOC_STAMP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); st_acc[i] += (unsigned)(t_ - st_prev); st_prev = t_; } while (0)
+#define VOC_STAMP_FRAME ++st_frames
+#define VOC_STAMP_FLUSH(kid) do { if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < kStampSlots; ++i_) atomicAdd(&voc_stamps[kid][i_], (unsigned long long)st_acc[i_]); atomicAdd(&voc_stamps[kid][kStampSlots], (unsigned long long)st_frames); } } while (0)
+#else
+#define VOC_STAMP_DECL
+#define VOC_STAMP(i)
+#define VOC_STAMP_FRAME
+#define VOC_STAMP_FLUSH(kid)
+#endif
+
 template <int LOG2M>
 struct FastCfg {
     static constexpr int M = 1 << LOG2M;
@@ -653,8 +671,11 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
         for (int u = 0; u < 8; ++u) xs[u] = sample_pair(fr, u, tid);
         load_window(tid);
     }
+    VOC_STAMP_DECL;
     for (long long f = fs; f < f1; ++f) {
         const bool emit = f >= f0;
+        VOC_STAMP_FRAME;
+        VOC_STAMP(0);
         fast_tw_touch<LOG2M>(tw);
         if (!(VEC2 && VOC_WS_PREFETCH) && f > fs) load_window(opaque_int(tid));  // predicated loads: not worth the registers of a prefetch
         wave_prio<VOC_PRIO_ANA_T, LOG2M>();
@@ -693,6 +714,7 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
             }
         });
 
+        VOC_STAMP(1);
         wave_prio<VOC_PRIO_ANA_B, LOG2M>();
         const long long row = c * a.rpc + f;
         R *mrow = a.mag + row * a.ldk, *irow = a.inc + row * a.ldk;
@@ -709,11 +731,14 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
         const C2 *zlo = lds + lds_sw(lt), *zhi = lds + lds_sw(M - lt);
         if constexpr (KEEP) {
             __syncthreads();  // the last pass' input has been read by everyone
+            VOC_STAMP(2);
             C2 *zw = lds + lds_sw(lt);
 #pragma unroll
             for (int n = 4; n < 8; ++n) zw[n * T] = v[nat_idx<LOG2M>(n)];
             zw[0] = v[nat_idx<LOG2M>(0)];  // thread 0's first pair is the self-paired bin M/2 (its own element 4 T), and Z[0] is read by two other threads
+            VOC_STAMP(3);
             __syncthreads();
+            VOC_STAMP(4);
         }
         // byte offsets of the pair's bins in an STFT row and in the phase array: slot 0 has its own, slots
         // 1..3 sit at +-(m - 2) T elements around one offset each (immediates of the memory instructions)
@@ -785,6 +810,7 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
             }
             *pk = phr;
         }
+        VOC_STAMP(5);
         // slide the sample window by one hop
 #pragma unroll
         for (int u = 0; u < 8 - NEW; ++u) xs[u] = xs[u + NEW];
@@ -793,6 +819,7 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
         // the next frame's first LDS write sits behind the first barrier of fft_after_first
     }
 
+    VOC_STAMP_FLUSH(0);
     if (f1 == a.F && f1 > f0) {
         __syncthreads();
         R *po = a.phase_out + c * p.K;
@@ -928,7 +955,10 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, (syn_fat<LOG2M, OLA, R>() ?
 #pragma unroll
         for (int j = 0; j < NP; ++j) wres[j] = at_bytes(reinterpret_cast<const C2 *>(VOC_SYN_WIN_SCALED ? p.window_n : p.window) + j * T, (unsigned)tid * (unsigned)sizeof(C2), 0);
     }
+    VOC_STAMP_DECL;
     for (long long f = fs; f < f1; ++f) {
+        VOC_STAMP_FRAME;
+        VOC_STAMP(0);
         const long long row = c * a.F + f;
         const int lt = opaque_int(tid);  // keeps this frame's index arithmetic inside the loop
         fast_tw_touch<LOG2M>(tw);
@@ -999,7 +1029,9 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, (syn_fat<LOG2M, OLA, R>() ?
         }
         if (SFAT && f + 1 < f1) load_row(f + 1, lt);
         wave_prio<VOC_PRIO_SYN_T, LOG2M>();
+        VOC_STAMP(1);
         __syncthreads();
+        VOC_STAMP(2);
         C2 v[8];
         if constexpr (KEEP_IN) {
 #pragma unroll
@@ -1033,6 +1065,7 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, (syn_fat<LOG2M, OLA, R>() ?
             for (int j = 0; j < NP; ++j) wv[j] = wres[j];
         }
         // lds[pad(m)] = swapped z[m]: v[2m] = z.y / N, v[2m+1] = z.x / N.  frame[i] = w[i] * v[(i + off + N/2) mod N]
+        VOC_STAMP(3);
         const bool emit = f >= f0;
         wave_prio<VOC_PRIO_SYN_O, LOG2M>();
         if (OLA) {
@@ -1082,8 +1115,11 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, (syn_fat<LOG2M, OLA, R>() ?
                 if (i < p.W) fo[(unsigned)i] = p.window[(unsigned)i] * s;
             }
         }
+        VOC_STAMP(4);
         __syncthreads();  // FFT buffer is rewritten by the next frame's spectrum
+        VOC_STAMP(5);
     }
+    VOC_STAMP_FLUSH(1);
 
     if (f1 == a.F && f1 > f0) {
         R *po = a.phase_out + c * p.K;

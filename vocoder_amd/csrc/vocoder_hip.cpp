@@ -20,6 +20,7 @@
 #include "../../include/vocoder_hip.h"
 #include "voc_kernels.h"
 #include "voc_kernels_fast.h"
+#include "voc_kernels_fast16.h"
 #include "voc_filters.h"
 #include "voc_kernels_bluestein.h"
 #include "voc_kernels_bluestein_big.h"
@@ -93,6 +94,9 @@ struct voc_ctx {
     void *static_scratch = nullptr;  // this device's copy of voc_static_scratch (allocation-free entry point)
     int ana_tile_override = 0, syn_tile_override = 0, syn_slots_override = 0;
     bool force_generic = false;  // VOC_FORCE_GENERIC=1: never take the specialised kernels
+    // sixteen instead of eight points per thread at N = 4096 / 8192 (voc_kernels_fast16.h): analysis by default
+    // (VOC_FAST16_ANA=0 turns it off), synthesis on request (VOC_FAST16_SYN=1: measured slower, kept for comparison)
+    bool fast16_ana = true, fast16_syn = false;
 #ifndef VOC_EMU
     bool profiling = false;
     struct Timed { int kind; hipEvent_t start, stop; };
@@ -555,6 +559,81 @@ void launch_synthesis(voc_ctx *c, const voc::SynArgsT<R> &a, long long channels,
 
 inline bool fast_sizes(const voc_ctx *c) { return !c->force_generic && !c->bluestein && c->log2m >= 9 && c->log2m <= 12; }
 
+// The kernels with sixteen points per thread (voc_kernels_fast16.h) serve double-precision contexts with
+// N = 4096 or 8192.  Whether a context's analysis takes them depends on the context alone -- never on the
+// alignment, the strides or the shape of one call's arrays -- so that every entry point of a context
+// (stages, signals, streams pushed in any chunking) produces the same bits.
+inline bool fast16_analysis(const voc_ctx *c)
+{
+    return c->fast16_ana && !c->force_generic && !c->bluestein && c->precision == VOC_PRECISION_F64 && (c->log2m == 11 || c->log2m == 12);
+}
+
+// The sixteen-point synthesis kernel needs W == N and a hop of 1, 2, 4 or 8 times N/16 samples.  Returns that
+// multiple (the pair slots its overlap-add emits per frame) or 0.
+inline int fast16_hop_slots(const voc_ctx *c, bool synthesis)
+{
+    if (!(synthesis ? c->fast16_syn : c->fast16_ana) || c->force_generic || c->bluestein || c->precision != VOC_PRECISION_F64) return 0;
+    if ((c->log2m != 11 && c->log2m != 12) || c->W != c->N) return 0;
+    const int t2 = c->M / 8;  // 2 T samples
+    if (c->H % t2 != 0) return 0;
+    const int s = c->H / t2;
+    return (s == 1 || s == 2 || s == 4 || s == 8) ? s : 0;
+}
+
+#ifdef VOC_DEV_ONLY_LOG2M
+#define VOC_FOR_EACH_FAST16_LOG2M(X) X(VOC_DEV_ONLY_LOG2M)
+#else
+#define VOC_FOR_EACH_FAST16_LOG2M(X) X(11) X(12)
+#endif
+
+template <int L>
+void launch_analysis_fast16(voc_ctx *c, const voc::AnaArgsT<double> &a, unsigned grid, bool vec2, int slide, hipStream_t st)
+{
+    const dim3 g(grid), b(voc::Fast16Cfg<L>::T);
+    const size_t lds = voc::Fast16Cfg<L>::template lds_bytes<double>();
+    if (!vec2) hipLaunchKernelGGL((voc::analysis_fast16_kernel<L, false, 0, double>), g, b, lds, st, c->params, a);
+    else if (slide == 1) hipLaunchKernelGGL((voc::analysis_fast16_kernel<L, true, 1, double>), g, b, lds, st, c->params, a);
+    else if (slide == 2) hipLaunchKernelGGL((voc::analysis_fast16_kernel<L, true, 2, double>), g, b, lds, st, c->params, a);
+    else if (slide == 4) hipLaunchKernelGGL((voc::analysis_fast16_kernel<L, true, 4, double>), g, b, lds, st, c->params, a);
+    else if (slide == 8) hipLaunchKernelGGL((voc::analysis_fast16_kernel<L, true, 8, double>), g, b, lds, st, c->params, a);
+    else hipLaunchKernelGGL((voc::analysis_fast16_kernel<L, true, 0, double>), g, b, lds, st, c->params, a);
+}
+
+template <int L, bool MAPPED>
+void launch_synthesis_fast16(voc_ctx *c, const voc::SynArgsT<double> &a, unsigned grid, int nhp, hipStream_t st)
+{
+    const dim3 g(grid), b(voc::Fast16Cfg<L>::T);
+    const size_t lds = voc::Fast16Cfg<L>::template lds_bytes<double>();
+    switch (nhp) {
+    case 1: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 1, double, MAPPED>), g, b, lds, st, c->params, a); break;
+    case 2: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 2, double, MAPPED>), g, b, lds, st, c->params, a); break;
+    case 4: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 4, double, MAPPED>), g, b, lds, st, c->params, a); break;
+    default: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 8, double, MAPPED>), g, b, lds, st, c->params, a); break;
+    }
+}
+
+#if defined(VOC_STAMPS) && !defined(VOC_EMU)
+// diagnostic builds: prints and clears the table of in-kernel time marks (voc_kernels_fast16.h)
+inline void print_stamps(const char *what, int kid)
+{
+    unsigned long long h[2][voc::kStampSlots + 1];
+    if (hipDeviceSynchronize() != hipSuccess) return;
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(voc::voc_stamps), sizeof(h)) != hipSuccess) return;
+    const double n = (double)h[kid][voc::kStampSlots];
+    if (n > 0) {
+        double total = 0;
+        for (int i = 0; i < voc::kStampSlots; ++i) total += (double)h[kid][i];
+        std::fprintf(stderr, "[stamps] %s: %.0f wave-frames, %.0f clocks per wave-frame:", what, n, total / n);
+        for (int i = 0; i < voc::kStampSlots; ++i) std::fprintf(stderr, " %d:%.0f", i, (double)h[kid][i] / n);
+        std::fprintf(stderr, "\n");
+    }
+    std::memset(h, 0, sizeof(h));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(voc::voc_stamps), h, sizeof(h));
+}
+#else
+inline void print_stamps(const char *, int) {}
+#endif
+
 // Specialised analysis kernel (polar output) when the frame length allows it.
 template <class R>
 bool launch_analysis_fast(voc_ctx *c, const voc::AnaArgsT<R> &a, long long channels, hipStream_t st)
@@ -565,6 +644,21 @@ bool launch_analysis_fast(voc_ctx *c, const voc::AnaArgsT<R> &a, long long chann
     if (grid > 0x7fffffffLL) throw HipFail{hipErrorInvalidValue, "analysis grid too large"};
     const bool vec2 = c->W == c->N && (reinterpret_cast<uintptr_t>(a.x) % (2 * sizeof(R)) == 0) && a.chan_stride % 2 == 0 &&
                       a.frame_stride % 2 == 0;
+    if constexpr (std::is_same<R, double>::value) {
+        if (fast16_analysis(c)) {
+            // frames cut from one signal, hop 1, 2, 4 or 8 times N/16: the sample window slides in registers
+            const int s16 = (vec2 && a.frame_stride == c->H) ? fast16_hop_slots(c, false) : 0;
+            LaunchTimer timer(c, KIND_ANALYSIS, st);
+            switch (c->log2m) {
+#define X(L) case L: launch_analysis_fast16<L>(c, a, (unsigned)grid, vec2, s16, st); break;
+                VOC_FOR_EACH_FAST16_LOG2M(X)
+#undef X
+            }
+            HIPCHK(hipGetLastError());
+            print_stamps("analysis16", 0);
+            return true;
+        }
+    }
     // frames cut from one signal, hop a multiple of 2T: the sample window slides in registers
     const int t2 = 2 * (c->M / 8);
     int slide = 0;
@@ -589,6 +683,7 @@ bool launch_analysis_fast(voc_ctx *c, const voc::AnaArgsT<R> &a, long long chann
 #undef X
     }
     HIPCHK(hipGetLastError());
+    print_stamps("analysis8", 0);
     return true;
 }
 
@@ -627,14 +722,32 @@ template <class R>
 bool launch_synthesis_fast(voc_ctx *c, const voc::SynArgsT<R> &a, long long channels, bool ola, hipStream_t st)
 {
     if (!fast_sizes(c)) return false;
+    const bool aligned16 = reinterpret_cast<uintptr_t>(a.out) % (2 * sizeof(R)) == 0 && a.out_stride % 2 == 0;
+    const int s16 = (ola && aligned16 && std::is_same<R, double>::value) ? fast16_hop_slots(c, true) : 0;
     const int nh = ola ? fast_ola_nhp(c, a) : 8;
-    if (ola && nh == 0) return false;
+    if (ola && nh == 0 && s16 == 0) return false;
     const bool mapped = a.mag_rows || a.inc_rows;
     if (mapped && !(ola && std::is_same<R, double>::value)) return false;  // the generic kernel reads through maps too
     const long long grid = a.unsplit + (channels - a.unsplit) * a.tiles;
     if (grid <= 0) return true;
     if (grid > 0x7fffffffLL) throw HipFail{hipErrorInvalidValue, "synthesis grid too large"};
     LaunchTimer timer(c, KIND_SYNTHESIS, st);
+    if constexpr (std::is_same<R, double>::value) {
+        if (s16 > 0) {
+            switch (c->log2m) {
+#define X(L)                                                                                     \
+    case L:                                                                                      \
+        if (mapped) launch_synthesis_fast16<L, true>(c, a, (unsigned)grid, s16, st);             \
+        else launch_synthesis_fast16<L, false>(c, a, (unsigned)grid, s16, st);                   \
+        break;
+                VOC_FOR_EACH_FAST16_LOG2M(X)
+#undef X
+            }
+            HIPCHK(hipGetLastError());
+            print_stamps("synthesis16", 1);
+            return true;
+        }
+    }
     switch (c->log2m) {
 #define X(L)                                                                          \
     case L:                                                                           \
@@ -647,6 +760,7 @@ bool launch_synthesis_fast(voc_ctx *c, const voc::SynArgsT<R> &a, long long chan
 #undef X
     }
     HIPCHK(hipGetLastError());
+    print_stamps("synthesis8", 1);
     return true;
 }
 
@@ -921,6 +1035,10 @@ long long synthesis_slots(const voc_ctx *c)
 {
     if (!fast_sizes(c)) return 0;
     if (c->syn_slots_override > 0) return c->syn_slots_override;  // VOC_SYN_SLOTS: lets small tests reach this path
+    if (fast16_hop_slots(c, true) > 0) {  // sixteen points per thread: M * 16 bytes of LDS and two waves per SIMD
+        const long long t16 = c->M / 16, by_lds16 = (long long)kLdsLimit / ((long long)c->M * 16), by_regs16 = 8 * 64 / t16;
+        return 256 * (by_lds16 < by_regs16 ? by_lds16 : by_regs16);
+    }
     const bool f32 = c->precision == VOC_PRECISION_F32;
     const long long t = c->M / 8;
     const long long lds = (long long)(c->M * 2 + ((c->K + 1) & ~1)) * (f32 ? 4 : 8);  // FastCfg::lds_bytes
@@ -1178,6 +1296,8 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
         c->syn_tile_override = env_int("VOC_SYN_TILE_LEN");
         c->syn_slots_override = env_int("VOC_SYN_SLOTS");
         c->force_generic = env_int("VOC_FORCE_GENERIC") != 0;
+        c->fast16_ana = !(std::getenv("VOC_FAST16_ANA") && env_int("VOC_FAST16_ANA") == 0);
+        c->fast16_syn = env_int("VOC_FAST16_SYN") != 0;
 
         // per-pass Stockham twiddles, laid out as voc::fft_passes reads them: the pass at stride NS
         // (radix r = min(8, M/NS)) occupies entries NS-1 .. NS-1 + (r-1)*NS, [j-1][k] with k fastest,
