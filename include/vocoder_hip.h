@@ -225,7 +225,8 @@ int32_t voc_roundtrip_dev(voc_ctx *ctx, const double *x, int64_t x_stride, int64
  * array: calls that overlap in time on one GPU race; order them on one HIP stream or
  * synchronise between them.  Nothing in the array has to be cleared between calls.  Frame lengths
  * above 4096 that are not powers of two return VOC_ERR_UNSUPPORTED here: their transforms go through a
- * buffer that the library allocates.
+ * buffer that the library allocates.  Launch timing (voc_profile_enable) records its launches with events
+ * it creates, so it is off for the duration of this call: voc_profile_read does not count them.
  */
 #define VOC_STATIC_SCRATCH_BYTES (64u << 20)
 int32_t voc_roundtrip_static_dev(voc_ctx *ctx, const double *x, int64_t x_stride, int64_t length, int64_t channels,

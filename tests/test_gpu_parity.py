@@ -87,6 +87,8 @@ def test_golden_fixtures(gpu_lib, path):
     (4096, 2048, 9, 1, 3, 3),      # hop N/2
     (8192, 2048, 12, 2, 0, 5),     # config 3 length
     (8192, 1024, 19, 1, 4, 4),
+    (16384, 4096, 8, 2, 0, 0),     # no eight-point kernels at this length: (0, 0) is the generic path through frames
+    (16384, 2048, 11, 1, 3, 4),
 ])
 def test_roundtrip_with_eight_and_sixteen_points_per_thread(gpu_lib, orc, monkeypatch, n, h, nf, c, at, st, ana16, syn16):
     """N = 4096 / 8192 have two builds of the specialised kernels: eight and sixteen complex points per thread
@@ -350,4 +352,62 @@ def test_calls_on_two_hip_streams_share_the_context_workspace(gpu_lib, orc):
     got = run([torch.cuda.Stream(), torch.cuda.Stream()])
     for (pa, fa), (pb, fb) in zip(ref, got):
         assert torch.equal(pa, pb) and torch.equal(fa, fb)
+    par.close()
+
+
+def test_chirp_z_calls_on_two_hip_streams_with_caller_workspaces(gpu_lib, orc):
+    """Frame lengths above 4096 that are not powers of two run their transforms through one buffer of the
+    context, whoever brings the workspace of the call: two streams must still be ordered for it."""
+    import torch
+    from vocoder_amd import vocoder as V, conduit as Cd
+    n, hop, c = 5000, 1250, 3
+    par = V.VocoderParams(n, hop, orc.make_window("hann", n), lib=gpu_lib)
+    length = n + hop * 9 + 6
+    f = Cd.num_frames(par, length)
+    rng = np.random.default_rng(5)
+    xs = [torch.from_numpy(rng.standard_normal((c, length))).cuda() for _ in range(2)]
+    wss = [torch.empty(Cd.roundtrip_workspace_bytes(par, length, c), dtype=torch.uint8, device="cuda") for _ in range(2)]
+
+    def run(streams):
+        outs = []
+        for x, ws, st in zip(xs, wss, streams):
+            y = torch.empty((c, Cd.ola_length(par, f, hop)), dtype=torch.float64, device="cuda")
+            aph = torch.zeros((c, par.K), dtype=torch.float64, device="cuda")
+            sph = torch.zeros_like(aph)
+            with torch.cuda.stream(st):
+                for _ in range(3):
+                    aph.zero_(); sph.zero_()
+                    Cd.process_dev(par, x, y, aph, sph, workspace=ws, stream=st.cuda_stream)
+            outs.append((y, aph, sph))
+        torch.cuda.synchronize()
+        return outs
+
+    torch.cuda.synchronize()
+    one = torch.cuda.Stream()
+    ref = run([one, one])
+    got = run([torch.cuda.Stream(), torch.cuda.Stream()])
+    for a, b in zip(ref, got):
+        assert all(torch.equal(u, v) for u, v in zip(a, b))
+    r = orc.roundtrip(n, hop, orc.make_window("hann", n), xs[0][0].cpu().numpy())
+    assert Hh.rel_l2(got[0][0][0].cpu().numpy(), r["y"]) <= Hh.TOL_L2
+    par.close()
+
+
+def test_analysis_step_equals_analysis_stage_on_a_length_that_is_not_a_power_of_two(gpu_lib, orc):
+    """analysisStep and analysisBlock of one context divide by the same N (Vocoder.hs:173): same bits."""
+    from vocoder_amd import vocoder as V
+    n, hop = 800, 200
+    win = orc.make_window("hann", n)
+    par = V.VocoderParams(n, hop, win, lib=gpu_lib)
+    rng = np.random.default_rng(11)
+    frames = rng.standard_normal((1, 1, n))
+    prev = rng.uniform(-3, 3, (1, par.K))
+    ph_stage, (mag_stage, inc_stage) = V.analysis_stage(par, prev, frames)
+    spec = V.do_fft(par, frames[0])
+    ph_step, (mag_step, inc_step) = V.analysis_step(par, prev, spec)
+    assert np.array_equal(ph_step[0], ph_stage[0]) and np.array_equal(inc_step[0], inc_stage[0, 0])
+    ph_hn, (mag_hn, inc_hn) = V.analysis_step(hop, n, prev, spec, lib=gpu_lib)
+    assert np.array_equal(inc_hn, inc_step)
+    rp, rm, ri = orc.analysis_step(hop, n, prev[0], spec[0])
+    assert Hh.circ_dist(inc_step[0] * hop, ri * hop).max() <= Hh.TOL_PHASE
     par.close()

@@ -75,6 +75,42 @@ def test_static_scratch_roundtrip_equals_workspace_roundtrip(gpu_lib, orc):
     par.close()
 
 
+def test_static_scratch_call_allocates_nothing_and_records_no_launch_times(gpu_lib):
+    """The entry point's contract: no device memory is taken by the call (free memory of the device is the same
+    before and after, with every tensor of the test allocated beforehand), and, launch timing being built on
+    events the library would have to create, the call's launches are not counted while it is on."""
+    import torch
+    from vocoder_amd import vocoder as V, conduit as Cd
+    n, hop = 4096, 1024
+    par = V.VocoderParams(n, hop, _hann(n), lib=gpu_lib)
+    c, length = 6, n + hop * 150
+    x = torch.randn((c, length), dtype=torch.float64, device="cuda")
+    y = torch.empty((c, Cd.ola_length(par, 151, hop)), dtype=torch.float64, device="cuda")
+    aph = torch.zeros((c, par.K), dtype=torch.float64, device="cuda")
+    sph = torch.zeros_like(aph)
+    Cd.process_static_dev(par, x, y, aph, sph)      # (first call on a context: nothing left to set up afterwards)
+    torch.cuda.synchronize()
+    par.lib.dll.voc_profile_enable(par.handle, 1)
+    ms, cnt = np.zeros(4), np.zeros(4, dtype=np.int64)
+    par.lib.dll.voc_profile_read(par.handle, ms.ctypes.data, cnt.ctypes.data)
+    free_before = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        Cd.process_static_dev(par, x, y, aph, sph)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before
+    par.lib.dll.voc_profile_read(par.handle, ms.ctypes.data, cnt.ctypes.data)
+    assert cnt.sum() == 0
+    # the same context with a library-owned workspace does take memory and is timed: the check can fail
+    ws_bytes = Cd.roundtrip_workspace_bytes(par, length, c)
+    Cd.process_dev(par, x, y, aph, sph)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] <= free_before - ws_bytes // 2
+    par.lib.dll.voc_profile_read(par.handle, ms.ctypes.data, cnt.ctypes.data)
+    assert cnt.sum() >= 2
+    par.lib.dll.voc_profile_enable(par.handle, 0)
+    par.close()
+
+
 def test_static_scratch_refuses_what_does_not_fit(gpu_lib):
     import torch
     from vocoder_amd import vocoder as V, conduit as Cd

@@ -448,8 +448,11 @@ VOC_DEV void fast_sincos(double x, double *sn, double *cs)
 // and its comparison with 2 pi are those of the exact remainder unless it lies within half an ulp
 // of 2 pi) then falls in [-2pi, 0) or [2pi, 4pi) instead of [0, 2pi), and floor(r0 / 2pi) is the
 // correction -- no compare, no select.  Only a remainder within an ulp of 2 pi (probability
-// ~2^-52 per call) can still be taken for a full turn: the result is then one turn off, i.e. -pi - tiny
-// instead of pi - tiny, the same angle.
+// ~2^-52 per call) can still be taken for a full turn: the result is then one turn off, -pi - tiny
+// instead of pi - tiny.  As an angle that is the same, but the increment built from it,
+// (omega + wrap) / H, is then 2 pi / H smaller than the reference's for that one bin and frame -- which
+// a filter that rescales or interpolates increments does not undo.  Accepted at that probability
+// (the metric workload makes 6e9 calls per pass: one such bin in about 10^6 passes).
 #ifndef VOC_WRAP8
 #define VOC_WRAP8 1
 #endif
@@ -567,7 +570,11 @@ VOC_DEV double bin_omega(const ParamsT<R> &p, int k)
 {
     if (p.omega1 != 0.0) return (double)k * p.omega1;
     asm volatile("");  // keeps this (uniform) branch a branch: as a select both sides would be computed
-    return ((kTwoPi * (double)k) * (double)p.hop_d) * (double)p.inv_n;
+    const double t = (kTwoPi * (double)k) * (double)p.hop_d;
+    // the reference divides by N (Vocoder.hs:173); a product with 1/N has the same bits only for a power of two
+    if ((p.N & (p.N - 1)) == 0) return t * (double)p.inv_n;
+    asm volatile("");
+    return t / (double)p.N;
 }
 
 VOC_DEV double phase_inc(const ParamsT<double> &p, int k, double ph_diff)

@@ -1,4 +1,4 @@
-// voc_kernels_fast16.h -- the hot-path kernels for N = 4096 and N = 8192 with SIXTEEN complex points per
+// voc_kernels_fast16.h -- kernels for N = 4096, 8192 and 16384 with SIXTEEN complex points per
 // thread (M = N/2 complex points, T = M/16 threads per frame, 8 (k, M-k) bin pairs per thread).
 //
 // Same arithmetic per bin and the same frame-to-frame state as the eight-point kernels of
@@ -6,11 +6,11 @@
 // 16-byte LDS write keeps its SIMD from issuing for about as long as seven fp64 instructions, so the
 // lever is the number of times a frame crosses LDS: with sixteen points per thread the M-point transform
 // is radix 16 * 16 * (M/256) -- three passes, TWO exchanges -- where eight points per thread need four
-// passes and three exchanges (M = 2048: 8 * 8 * 8 * 4).  The hand-over at both ends stays: the last pass
+// passes and three exchanges (M = 2048: 8 * 8 * 8 * 4).  N = 16384 (M = 8192) takes a fourth pass of radix 2.  The hand-over at both ends stays: the last pass
 // leaves element tid + n T with thread tid, which owns the bin pairs (tid + m T, M - tid - m T) and, in
 // synthesis, the output samples of exactly those elements.
 //
-// A workgroup is T = 128 (N = 4096) or 256 (N = 8192) threads and holds one frame in M * 16 bytes of LDS
+// A workgroup is T = 128 (N = 4096), 256 (N = 8192) or 512 (N = 16384) threads and holds one frame in M * 16 bytes of LDS
 // and nothing else: previous phases (analysis), accumulated phases and overlap-add partial sums
 // (synthesis) live in registers.  Four (two) workgroups fit a CU: two waves per SIMD, 256 registers each.
 #pragma once
@@ -21,12 +21,14 @@ namespace voc {
 
 template <int LOG2M>
 struct Fast16Cfg {
-    static_assert(LOG2M == 11 || LOG2M == 12, "sixteen points per thread: N = 4096 or 8192");
+    static_assert(LOG2M >= 11 && LOG2M <= 13, "sixteen points per thread: N = 4096, 8192 or 16384");
     static constexpr int M = 1 << LOG2M;
     static constexpr int T = M / 16;
     static constexpr int K = M + 1;
-    static constexpr int R3 = M / 256;     // radix of the third pass
-    static constexpr int NB3 = 16 / R3;    // third-pass butterflies per thread
+    static constexpr bool PASS4 = LOG2M == 13;           // M = 8192: radix 16 * 16 * 16 * 2
+    static constexpr int R3 = PASS4 ? 16 : M / 256;      // radix of the third pass
+    static constexpr int NB3 = 16 / R3;                  // third-pass butterflies per thread
+    static constexpr int NC = PASS4 ? 2 : NB3;           // twiddle bases of the passes after the second
     template <class R> static constexpr int lds_bytes() { return M * 2 * (int)sizeof(R); }
 };
 
@@ -38,11 +40,13 @@ struct Fast16Cfg {
 VOC_DEV int lds_sw16(int i) { return i ^ ((i >> 4) & 7); }
 
 // where element tid + n T of the last pass' result sits in the thread's registers: butterfly q of the
-// thread (q < NB3) produces the elements tid + (q + j NB3) T
+// thread (q < NB3) produces the elements tid + (q + j NB3) T; with a fourth pass (radix 2, eight butterflies
+// per thread) butterfly q produces the elements tid + (q + 8 j) T
 template <int LOG2M>
 VOC_DEV constexpr int nat16(int n)
 {
     constexpr int R3 = Fast16Cfg<LOG2M>::R3, NB3 = Fast16Cfg<LOG2M>::NB3;
+    if (Fast16Cfg<LOG2M>::PASS4) return (n % 8) * 2 + n / 8;
     return (n % NB3) * R3 + n / NB3;
 }
 
@@ -100,7 +104,8 @@ VOC_DEV void dft16(C2 (&v)[16], C2 w1)
 template <int LOG2M, class C2>
 struct Fast16Tw {
     C2 b;                               // pass at stride 16: exp(-2 pi i (tid mod 16) / 256)
-    C2 c[Fast16Cfg<LOG2M>::NB3];        // pass at stride 256: exp(-2 pi i (tid + q T) / M), one per butterfly
+    C2 c[Fast16Cfg<LOG2M>::NC];         // pass at stride 256: exp(-2 pi i (tid + q T) / M), one per butterfly (with a fourth
+                                        // pass: exp(-2 pi i (tid mod 256) / 4096), then exp(-2 pi i tid / M) for the pass at stride 4096)
     C2 s;                               // exp(-2 pi i tid / N): base of the split twiddles
 };
 
@@ -110,8 +115,13 @@ VOC_DEV void fast16_tw_init(const ParamsT<R> &p, int tid, Fast16Tw<LOG2M, cplx<R
     constexpr int M = Fast16Cfg<LOG2M>::M, T = Fast16Cfg<LOG2M>::T;
     // twS[k] = exp(-2 pi i k / N), k <= M/2
     t.b = p.twS[(tid & 15) * (M / 128)];
+    if constexpr (Fast16Cfg<LOG2M>::PASS4) {
+        t.c[0] = p.twS[(tid & 255) * (M / 2048)];
+        t.c[1] = p.twS[2 * tid];
+    } else {
 #pragma unroll
-    for (int q = 0; q < Fast16Cfg<LOG2M>::NB3; ++q) t.c[q] = p.twS[2 * ((tid + q * T) & 255)];
+        for (int q = 0; q < Fast16Cfg<LOG2M>::NB3; ++q) t.c[q] = p.twS[2 * ((tid + q * T) & 255)];
+    }
     t.s = p.twS[tid];
 }
 
@@ -121,7 +131,7 @@ VOC_DEV void fast16_tw_touch(Fast16Tw<LOG2M, C2> &t)
 {
     opaque(t.b);
 #pragma unroll
-    for (int q = 0; q < Fast16Cfg<LOG2M>::NB3; ++q) opaque(t.c[q]);
+    for (int q = 0; q < Fast16Cfg<LOG2M>::NC; ++q) opaque(t.c[q]);
     opaque(t.s);
 }
 
@@ -168,25 +178,54 @@ VOC_DEV void store16_second(C2 *lds, int lt, const C2 (&v)[16])
 }
 
 // third pass (stride 256): butterfly lt + q T reads the elements lt + (q + j NB3) T and leaves its results,
-// the same elements of the transform, in place: element lt + n T at v[nat16(n)]
+// the same elements of the transform, in place: element lt + n T at v[nat16(n)].
+// With a fourth pass (M = 8192): the third pass' butterfly lt (radix 16) writes the elements
+// 4096 (lt / 256) + k + 256 j, k = lt mod 256 (their swizzle bits are those of k), and the fourth pass'
+// butterflies lt + q T, q = 0..7 (radix 2, stride 4096) read the elements lt + q T and lt + (q + 8) T and leave
+// them in place.
 template <int LOG2M, class C2>
-VOC_DEV void pass3_16(const C2 *lds, const Fast16Tw<LOG2M, C2> &t, int lt, C2 (&v)[16])
+VOC_DEV void pass3_16(C2 *lds, const Fast16Tw<LOG2M, C2> &t, int lt, C2 (&v)[16])
 {
+    using R = decltype(v[0].x);
     constexpr int T = Fast16Cfg<LOG2M>::T, R3 = Fast16Cfg<LOG2M>::R3, NB3 = Fast16Cfg<LOG2M>::NB3;
     const C2 *src = lds + lds_sw16(lt);
-#pragma unroll
-    for (int n = 0; n < 16; ++n) v[nat16<LOG2M>(n)] = src[n * T];
-    if constexpr (R3 == 16) {
+    if constexpr (Fast16Cfg<LOG2M>::PASS4) {
+        load16<LOG2M>(lds, lt, v);
         dft16<true>(v, t.c[0]);
+        __syncthreads();
+        {
+            const int k = lt & 255;
+            C2 *dst = lds + (lt - k) * 16 + lds_sw16(k);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) dst[256 * j] = v[j];
+        }
+        __syncthreads();
+        // factor of butterfly lt + q T: exp(-2 pi i (lt + q T) / M) = c[1] exp(-2 pi i q / 16)
+        constexpr double cs[5] = {1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173, 0.0};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const C2 g = q <= 4 ? mk2((R)cs[q], (R)-cs[4 - q]) : mk2((R)-cs[8 - q], (R)-cs[q - 4]);
+            const C2 w = q == 0 ? t.c[1] : cmul(t.c[1], g);
+            C2 a, b;
+            bf2_tw(src[q * T], src[(q + 8) * T], w, a, b);
+            v[2 * q] = a;
+            v[2 * q + 1] = b;
+        }
     } else {
 #pragma unroll
-        for (int q = 0; q < NB3; ++q) {
-            C2 w[R3];
+        for (int n = 0; n < 16; ++n) v[nat16<LOG2M>(n)] = src[n * T];
+        if constexpr (R3 == 16) {
+            dft16<true>(v, t.c[0]);
+        } else {
 #pragma unroll
-            for (int j = 0; j < R3; ++j) w[j] = v[q * R3 + j];
-            dft8_tw(w, t.c[q]);
+            for (int q = 0; q < NB3; ++q) {
+                C2 w[R3];
 #pragma unroll
-            for (int j = 0; j < R3; ++j) v[q * R3 + j] = w[j];
+                for (int j = 0; j < R3; ++j) w[j] = v[q * R3 + j];
+                dft8_tw(w, t.c[q]);
+#pragma unroll
+                for (int j = 0; j < R3; ++j) v[q * R3 + j] = w[j];
+            }
         }
     }
 }

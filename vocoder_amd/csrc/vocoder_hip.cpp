@@ -93,10 +93,13 @@ struct voc_ctx {
     bool ws_busy = false;
     void *static_scratch = nullptr;  // this device's copy of voc_static_scratch (allocation-free entry point)
     int ana_tile_override = 0, syn_tile_override = 0, syn_slots_override = 0;
+    int cus = 256;                       // compute units and LDS bytes per compute unit of the context's device
+    long long lds_per_cu = 160 * 1024;   // (read from the device's properties when the context is created)
     bool force_generic = false;  // VOC_FORCE_GENERIC=1: never take the specialised kernels
     // sixteen instead of eight points per thread at N = 4096 / 8192 (voc_kernels_fast16.h): analysis by default
     // (VOC_FAST16_ANA=0 turns it off), synthesis on request (VOC_FAST16_SYN=1: measured slower, kept for comparison)
-    bool fast16_ana = true, fast16_syn = false;
+    bool fast16_ana = true;
+    int fast16_syn = -1;  // -1: only where there is no eight-point kernel (N = 16384)
 #ifndef VOC_EMU
     bool profiling = false;
     struct Timed { int kind; hipEvent_t start, stop; };
@@ -563,27 +566,32 @@ inline bool fast_sizes(const voc_ctx *c) { return !c->force_generic && !c->blues
 // N = 4096 or 8192.  Whether a context's analysis takes them depends on the context alone -- never on the
 // alignment, the strides or the shape of one call's arrays -- so that every entry point of a context
 // (stages, signals, streams pushed in any chunking) produces the same bits.
-inline bool fast16_analysis(const voc_ctx *c)
+inline bool fast16_sizes(const voc_ctx *c)
 {
-    return c->fast16_ana && !c->force_generic && !c->bluestein && c->precision == VOC_PRECISION_F64 && (c->log2m == 11 || c->log2m == 12);
+    return !c->force_generic && !c->bluestein && c->precision == VOC_PRECISION_F64 && c->log2m >= 11 && c->log2m <= 13;
 }
 
-// The sixteen-point synthesis kernel needs W == N and a hop of 1, 2, 4 or 8 times N/16 samples.  Returns that
-// multiple (the pair slots its overlap-add emits per frame) or 0.
+inline bool fast16_analysis(const voc_ctx *c) { return c->fast16_ana && fast16_sizes(c); }
+
+// The sixteen-point synthesis kernel (overlap-add in registers) needs W == N and a hop of 1, 2, 4 or 8 times
+// N/16 samples.  Returns that multiple (the pair slots its overlap-add emits per frame) or 0.
 inline int fast16_hop_slots(const voc_ctx *c, bool synthesis)
 {
-    if (!(synthesis ? c->fast16_syn : c->fast16_ana) || c->force_generic || c->bluestein || c->precision != VOC_PRECISION_F64) return 0;
-    if ((c->log2m != 11 && c->log2m != 12) || c->W != c->N) return 0;
+    if (!fast16_sizes(c) || c->W != c->N) return 0;
+    if (synthesis ? !(c->fast16_syn == 1 || (c->fast16_syn < 0 && c->log2m == 13)) : !c->fast16_ana) return 0;
     const int t2 = c->M / 8;  // 2 T samples
     if (c->H % t2 != 0) return 0;
     const int s = c->H / t2;
     return (s == 1 || s == 2 || s == 4 || s == 8) ? s : 0;
 }
 
+template <class R>
+inline bool rows_aligned16(const R *y, long long stride) { return reinterpret_cast<uintptr_t>(y) % (2 * sizeof(R)) == 0 && stride % 2 == 0; }
+
 #ifdef VOC_DEV_ONLY_LOG2M
 #define VOC_FOR_EACH_FAST16_LOG2M(X) X(VOC_DEV_ONLY_LOG2M)
 #else
-#define VOC_FOR_EACH_FAST16_LOG2M(X) X(11) X(12)
+#define VOC_FOR_EACH_FAST16_LOG2M(X) X(11) X(12) X(13)
 #endif
 
 template <int L>
@@ -638,7 +646,7 @@ inline void print_stamps(const char *, int) {}
 template <class R>
 bool launch_analysis_fast(voc_ctx *c, const voc::AnaArgsT<R> &a, long long channels, hipStream_t st)
 {
-    if (!fast_sizes(c)) return false;
+    if (!fast_sizes(c) && !fast16_analysis(c)) return false;
     const long long grid = channels * a.tiles;
     if (grid <= 0) return true;
     if (grid > 0x7fffffffLL) throw HipFail{hipErrorInvalidValue, "analysis grid too large"};
@@ -659,6 +667,7 @@ bool launch_analysis_fast(voc_ctx *c, const voc::AnaArgsT<R> &a, long long chann
             return true;
         }
     }
+    if (!fast_sizes(c)) return false;
     // frames cut from one signal, hop a multiple of 2T: the sample window slides in registers
     const int t2 = 2 * (c->M / 8);
     int slide = 0;
@@ -721,9 +730,8 @@ inline voc::SynArgsT<double> as_double_args(const voc::SynArgsT<float> &) { retu
 template <class R>
 bool launch_synthesis_fast(voc_ctx *c, const voc::SynArgsT<R> &a, long long channels, bool ola, hipStream_t st)
 {
-    if (!fast_sizes(c)) return false;
-    const bool aligned16 = reinterpret_cast<uintptr_t>(a.out) % (2 * sizeof(R)) == 0 && a.out_stride % 2 == 0;
-    const int s16 = (ola && aligned16 && std::is_same<R, double>::value) ? fast16_hop_slots(c, true) : 0;
+    const int s16 = (ola && rows_aligned16(a.out, a.out_stride) && std::is_same<R, double>::value) ? fast16_hop_slots(c, true) : 0;
+    if (!fast_sizes(c) && s16 == 0) return false;
     const int nh = ola ? fast_ola_nhp(c, a) : 8;
     if (ola && nh == 0 && s16 == 0) return false;
     const bool mapped = a.mag_rows || a.inc_rows;
@@ -748,6 +756,7 @@ bool launch_synthesis_fast(voc_ctx *c, const voc::SynArgsT<R> &a, long long chan
             return true;
         }
     }
+    if (!fast_sizes(c)) return false;
     switch (c->log2m) {
 #define X(L)                                                                          \
     case L:                                                                           \
@@ -966,7 +975,8 @@ void synthesis_signal_dev(voc_ctx *c, const R *mag, const R *inc, long long ldk,
 {
     if (C <= 0 || F <= 0) return;
     WsUse use(c, st);
-    const bool fused = !c->bluestein && lds_bytes<R>(c, true) <= kLdsLimit;
+    const bool fused = !c->bluestein && (lds_bytes<R>(c, true) <= kLdsLimit ||
+                                         (std::is_same<R, double>::value && fast16_hop_slots(c, true) > 0 && rows_aligned16(y, y_stride)));
     const int halo = fused ? (c->W + c->H - 1) / c->H - 1 : 0;
     int tile_len, tiles;
     synthesis_tiling(c, C, F, halo, &tile_len, &tiles);
@@ -1033,20 +1043,21 @@ void phase_advance_dev(voc_ctx *c, const R *inc, long long ldk, long long F, lon
 // Workgroups of the specialised synthesis kernel the chip holds at once (0: the generic kernel runs).
 long long synthesis_slots(const voc_ctx *c)
 {
-    if (!fast_sizes(c)) return 0;
+    if (!fast_sizes(c) && fast16_hop_slots(c, true) == 0) return 0;
     if (c->syn_slots_override > 0) return c->syn_slots_override;  // VOC_SYN_SLOTS: lets small tests reach this path
     if (fast16_hop_slots(c, true) > 0) {  // sixteen points per thread: M * 16 bytes of LDS and two waves per SIMD
-        const long long t16 = c->M / 16, by_lds16 = (long long)kLdsLimit / ((long long)c->M * 16), by_regs16 = 8 * 64 / t16;
-        return 256 * (by_lds16 < by_regs16 ? by_lds16 : by_regs16);
+        const long long t16 = c->M / 16, by_lds16 = c->lds_per_cu / ((long long)c->M * 16), by_regs16 = 8 * 64 / t16;
+        const long long per_cu16 = by_lds16 < by_regs16 ? by_lds16 : by_regs16;
+        return c->cus * (per_cu16 < 1 ? 1 : per_cu16);
     }
     const bool f32 = c->precision == VOC_PRECISION_F32;
     const long long t = c->M / 8;
     const long long lds = (long long)(c->M * 2 + ((c->K + 1) & ~1)) * (f32 ? 4 : 8);  // FastCfg::lds_bytes
     const bool fat = VOC_SYN_FAT != 0 && c->log2m >= 10 && !f32;  // voc::syn_fat: two waves per SIMD instead of three
-    long long by_lds = (long long)kLdsLimit / lds, by_regs = (f32 ? 16 : (fat ? 8 : 12)) * 64 / t;
+    long long by_lds = c->lds_per_cu / lds, by_regs = (f32 ? 16 : (fat ? 8 : 12)) * 64 / t;
     long long per_cu = by_lds < by_regs ? by_lds : by_regs;
     if (per_cu < 1) per_cu = 1;
-    return 256 * per_cu;
+    return c->cus * per_cu;
 }
 
 // With more channels than the chip holds workgroups, whole rounds of channels need no cut at all:
@@ -1094,14 +1105,16 @@ struct RtPlan {
     size_t per_channel_bytes;  // STFT + carry + two phase snapshots (+ frames when not fused)
 };
 
-RtPlan roundtrip_plan(const voc_ctx *c, long long len, long long group, long long chunk)
+// ola16: the overlap-add of this call can run in the registers of the sixteen-point synthesis kernel (a frame
+// length whose ring does not fit in LDS is then fused all the same)
+RtPlan roundtrip_plan(const voc_ctx *c, long long len, long long group, long long chunk, bool ola16 = false)
 {
     RtPlan r{};
     r.F = num_frames(c, len);
     r.out_len = ola_length(c, r.F, chunk > 0 ? chunk : c->H);
     r.ldk = (c->K + 1) & ~1LL;
     const bool f32 = c->precision == VOC_PRECISION_F32;
-    r.fused_ola = !c->bluestein && (f32 ? lds_bytes<float>(c, true) : lds_bytes<double>(c, true)) <= kLdsLimit;
+    r.fused_ola = !c->bluestein && ((f32 ? lds_bytes<float>(c, true) : lds_bytes<double>(c, true)) <= kLdsLimit || ola16);
     r.halo = r.fused_ola ? (c->W + c->H - 1) / c->H - 1 : 0;
     if (r.F > 0) {
         r.ana_tile = analysis_tile_len(c, group, r.F);
@@ -1129,28 +1142,31 @@ void roundtrip_dev(voc_ctx *c, const R *x, long long x_stride, long long len, lo
                                 hipMemcpyDeviceToDevice, st));
     if (F <= 0) return;
 
+    const bool ola16 = std::is_same<R, double>::value && fast16_hop_slots(c, true) > 0 && rows_aligned16(y, y_stride);
     // channels per pass: as many as the workspace holds
     long long group = C;
     std::optional<WsUse> own;  // the library's own workspace is shared between calls; a caller's is the caller's to order
+    // (the chirp-z transform of long frames runs through one more buffer of the context, big_ws, whoever brings
+    //  the workspace: calls on two streams are ordered for it all the same)
+    if (!ws || c->blue_big) own.emplace(c, st);
     if (!ws) {
-        own.emplace(c, st);
         size_t cap = (size_t)160 << 30;
         const int cap_gb = env_int("VOC_WS_CAP_GB");
         if (cap_gb > 0) cap = (size_t)cap_gb << 30;
-        while (group > 1 && roundtrip_plan(c, len, group, chunk).per_channel_bytes * (size_t)group > cap)
+        while (group > 1 && roundtrip_plan(c, len, group, chunk, ola16).per_channel_bytes * (size_t)group > cap)
             group = (group + 1) / 2;
-        ensure_ws(c, roundtrip_plan(c, len, group, chunk).per_channel_bytes * (size_t)group);
+        ensure_ws(c, roundtrip_plan(c, len, group, chunk, ola16).per_channel_bytes * (size_t)group);
         ws = c->ws;
     } else {
-        while (group > 1 && roundtrip_plan(c, len, group, chunk).per_channel_bytes * (size_t)group > (size_t)ws_bytes)
+        while (group > 1 && roundtrip_plan(c, len, group, chunk, ola16).per_channel_bytes * (size_t)group > (size_t)ws_bytes)
             group = (group + 1) / 2;
-        if (roundtrip_plan(c, len, group, chunk).per_channel_bytes * (size_t)group > (size_t)ws_bytes)
+        if (roundtrip_plan(c, len, group, chunk, ola16).per_channel_bytes * (size_t)group > (size_t)ws_bytes)
             throw StatusFail{VOC_ERR_SIZE};  // workspace smaller than one channel needs
     }
 
     for (long long c0 = 0; c0 < C; c0 += group) {
         const long long G = (C - c0 < group) ? C - c0 : group;
-        const RtPlan r = roundtrip_plan(c, len, group, chunk);
+        const RtPlan r = roundtrip_plan(c, len, group, chunk, ola16);
         R *mag = static_cast<R *>(ws);
         R *inc = mag + (size_t)G * F * r.ldk;
         R *pinA = inc + (size_t)G * F * r.ldk;
@@ -1271,6 +1287,14 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
         if (device < 0 || device >= ndev) return VOC_ERR_INVALID;
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipEventCreateWithFlags(&c->ws_event, hipEventDisableTiming));
+#ifndef VOC_EMU
+        {   // how many workgroups the device holds at once follows from these (synthesis_slots)
+            hipDeviceProp_t prop;
+            HIPCHK(hipGetDeviceProperties(&prop, device));
+            if (prop.multiProcessorCount > 0) c->cus = prop.multiProcessorCount;
+            if (prop.maxSharedMemoryPerMultiProcessor > 0) c->lds_per_cu = (long long)prop.maxSharedMemoryPerMultiProcessor;
+        }
+#endif
         // every GPU holds its own copy of the static scratch array at its own address: look it up with
         // this context's device current and use only that pointer from here on
         HIPCHK(hipGetSymbolAddress(&c->static_scratch, HIP_SYMBOL(voc_static_scratch)));
@@ -1297,7 +1321,7 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
         c->syn_slots_override = env_int("VOC_SYN_SLOTS");
         c->force_generic = env_int("VOC_FORCE_GENERIC") != 0;
         c->fast16_ana = !(std::getenv("VOC_FAST16_ANA") && env_int("VOC_FAST16_ANA") == 0);
-        c->fast16_syn = env_int("VOC_FAST16_SYN") != 0;
+        c->fast16_syn = std::getenv("VOC_FAST16_SYN") ? (env_int("VOC_FAST16_SYN") != 0 ? 1 : 0) : -1;
 
         // per-pass Stockham twiddles, laid out as voc::fft_passes reads them: the pass at stride NS
         // (radix r = min(8, M/NS)) occupies entries NS-1 .. NS-1 + (r-1)*NS, [j-1][k] with k fastest,
