@@ -7,12 +7,12 @@ cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 out=gpurun_out/profile
 rm -rf $out && mkdir -p $out
 timeout -k 10 400 python3 bench.py > $out/bench.json || exit 1
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --no-cpu-baseline > $out/bench_under_rocprof.json || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --no-cpu-baseline --no-parity > $out/bench_under_rocprof.json || exit 1
 find $out/kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats.csv
 rm -rf $out/kt
 pass() {  # target file, counters...
     local target=$1; shift
-    timeout -s KILL 300 rocprofv3 --pmc "$@" --output-format csv -d $out/pmc_run -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 > /dev/null || return 1
+    timeout -s KILL 300 rocprofv3 --pmc "$@" --output-format csv -d $out/pmc_run -- python3 bench.py --no-cpu-baseline --no-parity --steps 3 --warmup 1 > /dev/null || return 1
     find $out/pmc_run -name "*counter_collection.csv" | head -1 | xargs -I{} python3 tools/pmc_summary.py {} --json $out/pmc.json >> $out/$target
     rm -rf $out/pmc_run
 }
