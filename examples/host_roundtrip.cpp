@@ -5,11 +5,27 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <string>
+#include <vector>
 
 #include "vocoder.hpp"
 
-int main()
+// With a directory as its argument the program also leaves what it computed there -- the input, the fused
+// output, the stage-by-stage output, the filtered output, the window -- as raw doubles, for a checker that
+// holds them against a CPU restatement of the reference (tests/test_gpu_cpp_host.py).
+static void dump(const char *dir, const char *name, const std::vector<double> &v)
 {
+    if (!dir) return;
+    const std::string path = std::string(dir) + "/" + name + ".f64";
+    if (FILE *f = std::fopen(path.c_str(), "wb")) {
+        std::fwrite(v.data(), sizeof(double), v.size(), f);
+        std::fclose(f);
+    }
+}
+
+int main(int argc, char **argv)
+{
+    const char *out_dir = argc > 1 ? argv[1] : nullptr;
     const int n = 2048, h = 512;
     vocoder::Window win(n);
     for (int k = 0; k < n; ++k) win[k] = 0.5 * (1 - std::cos(2 * M_PI * k / n));  // periodic Hann: exact overlap-add
@@ -93,6 +109,13 @@ int main()
     auto y2r = fast.flush();
     std::printf("playSpeed 2 in a stream: %zu samples out for %lld in\n", y2x.size() + y2r.size(), (long long)len);
     const bool speed_ok = y2x.size() + y2r.size() > (size_t)(2 * (len - 2 * n));
+    dump(out_dir, "window", std::vector<double>(win.begin(), win.end()));
+    dump(out_dir, "x", x);
+    dump(out_dir, "y_fused", r.y);
+    dump(out_dir, "y_stages", y);
+    dump(out_dir, "y_lowpass1000_amplify0.5", y2);
+    y2x.insert(y2x.end(), y2r.begin(), y2r.end());
+    dump(out_dir, "y_playspeed2", y2x);
     return (err < 1e-9 && diff < 1e-12 && same && ferr < 1e-3 && step_diff < 1e-12 && polar_diff < 1e-12 && add_diff < 1e-12 &&
             speed_ok) ? 0 : 1;
 }

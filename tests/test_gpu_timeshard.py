@@ -190,3 +190,91 @@ def test_fused_analysis_accuracy_is_as_stated(gpu_lib, orc, n, hop):
         d = np.abs(aph[ch] - pho) % (2 * np.pi)
         assert np.minimum(d, 2 * np.pi - d)[big[-1]].max() <= 1e-12
     par.close()
+
+
+class _ThreadComm:
+    """The exchange step of `process_pieces` between ranks that are threads of one process (one GPU)."""
+
+    def __init__(self, shared, rank):
+        self.s, self.rank, self.world = shared, rank, shared["world"]
+
+    def all_gather(self, total):
+        self.s["totals"][self.rank] = total.clone()
+        self.s["bar"].wait()
+        out = [t.clone() for t in self.s["totals"]]
+        self.s["bar"].wait()
+        return out
+
+    def neighbour_exchange(self, send, recv):
+        if send is not None and self.rank + 1 < self.world:
+            self.s["tails"][self.rank + 1] = send.clone()
+        self.s["bar"].wait()
+        if recv is not None:
+            recv.copy_(self.s["tails"][self.rank])
+        self.s["bar"].wait()
+
+    def broadcast_from_last(self, tensors):
+        if self.rank == self.world - 1:
+            self.s["last"] = [t.clone() for t in tensors]
+        self.s["bar"].wait()
+        for t, v in zip(tensors, self.s["last"]):
+            t.copy_(v)
+        self.s["bar"].wait()
+
+
+@pytest.mark.parametrize("chain", [[("envelope", 32)], [("pitch_shift", 2.0), ("lowpass_brickwall", 1000.0)], []],
+                         ids=["envelope32", "pitch2+lowpass1000", "identity"])
+def test_four_time_segments_with_a_filter_chain_match_the_oracle(gpu_lib, orc, chain):
+    """`--envelope 32` (and `--pitchShiftInterpolate 2 --lowpassBrickwall 1000`) on a signal cut by time over four
+    ranks, N = 4096, hop 1024, every rank walking its segment in runs of frames (`process_pieces`: the walk for the
+    phase advance, the all-gather, the output walk, the tail exchange -- one walk for `envelope`, whose increments
+    are zero, Filter.hs:73,144-152), against the sequential reference pipeline with that filter.  The ranks are
+    four threads on the one GPU; the exchange goes through `_ThreadComm`."""
+    import threading
+    import torch
+    from helpers import oracle_filtered
+    from vocoder_amd import vocoder as V, timeshard as T, filter as Fl
+    n, hop, world, piece, c = 4096, 1024, 4, 5, 2
+    win = _hann(n)
+    par = V.VocoderParams(n, hop, win, lib=gpu_lib)
+    length = n + hop * (13 * world + 1) + 9
+    x = _signal(c, length)
+    xt = torch.from_numpy(x).cuda()
+    f = Fl.id_filter()
+    for name, *prm in chain:
+        fn = {"pitch_shift": Fl.pitch_shift_interpolate, "envelope": Fl.envelope_filter}.get(name) or getattr(Fl, name)
+        f = Fl.compose_filters(f, fn(*prm))
+    filt = f.bind(par, 48000.0 / n) if chain else None
+    shared = {"world": world, "bar": threading.Barrier(world), "totals": [None] * world, "tails": [None] * world, "last": None}
+    results, reads, errors = [None] * world, [[] for _ in range(world)], []
+
+    def rank_main(r):
+        try:
+            def source(lo, hi):
+                reads[r].append((lo, hi))
+                return xt[:, lo:hi].contiguous()
+            results[r] = T.process_pieces(par, source, length, piece, filt=filt, comm=_ThreadComm(shared, r))
+        except BaseException as e:      # a failed rank must not leave the others waiting at a barrier
+            errors.append(e)
+            shared["bar"].abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    torch.cuda.synchronize()
+    y = torch.cat([res[0] for res in results], dim=1).cpu().numpy()
+    walks = 1 if any(s[0] == "envelope" for s in chain) else 2
+    for r in range(world):
+        sp = T.plan(par, length, world, r)
+        assert len(reads[r]) == walks * len(T.pieces_of(par, sp, piece))
+        assert torch.equal(results[r][1][0], results[0][1][0]) and torch.equal(results[r][1][1], results[0][1][1])
+    for ch in range(c):
+        ref = oracle_filtered(orc, n, hop, win, x[ch], 48000.0 / n, chain)
+        assert y.shape[1] == ref["y"].size
+        assert np.linalg.norm(y[ch] - ref["y"]) / np.linalg.norm(ref["y"]) <= TOL_L2
+        assert _wrap_err(results[0][1][0][ch].cpu().numpy(), ref["ana_phase"]) <= 1e-9
+        assert _wrap_err(results[0][1][1][ch].cpu().numpy(), ref["syn_phase"]) <= 1e-9
+    par.close()

@@ -287,7 +287,7 @@ def _timed(stats, fn, device):
 
 
 def process_pieces(par, source, length: int, piece_frames: int, sink=None, filt=None, chunk: int | None = None,
-                   ana_phase=None, syn_phase=None, group=None, stats=None):
+                   ana_phase=None, syn_phase=None, group=None, stats=None, comm=None):
     """Time-sharded round trip of a signal too long to hold its STFT: every rank walks its segment
     in runs of about `piece_frames` frames, so device memory holds one run's samples and STFT.
 
@@ -306,6 +306,11 @@ def process_pieces(par, source, length: int, piece_frames: int, sink=None, filt=
     across a run boundary adds the older run's partial sums first (Frames.hs:52-58), which
     re-associates that sum of at most W/H terms by one rounding.
 
+    comm: the exchange step, for callers that do not run one process per rank under torch.distributed (ranks as
+    threads of one process on one device, say): an object with `world`, `rank`, `all_gather(total) -> list of
+    every rank's total in rank order`, `neighbour_exchange(send_or_None, recv_or_None)` (send goes to rank + 1,
+    recv is filled from rank - 1) and `broadcast_from_last(tensors)` (in place).  None: torch.distributed.
+
     stats: an optional dict; the seconds spent in the two exchanges (all-gather, neighbour tails and
     the final phase broadcast, device-synchronised on both sides) are added to stats["exchange_s"].
 
@@ -314,9 +319,12 @@ def process_pieces(par, source, length: int, piece_frames: int, sink=None, filt=
     import torch
     import torch.distributed as dist
 
-    multi = dist.is_initialized() and dist.get_world_size(group) > 1
-    world = dist.get_world_size(group) if multi else 1
-    rank = dist.get_rank(group) if multi else 0
+    if comm is not None:
+        world, rank = comm.world, comm.rank
+    else:
+        multi = dist.is_initialized() and dist.get_world_size(group) > 1
+        world = dist.get_world_size(group) if multi else 1
+        rank = dist.get_rank(group) if multi else 0
     chunk = par.H if chunk is None else chunk
     sp = plan(par, length, world, rank, chunk)
     F = sp.frames_total
@@ -353,7 +361,8 @@ def process_pieces(par, source, length: int, piece_frames: int, sink=None, filt=
             par._call("voc_phase_advance_dev", _ptr(inc), inc.shape[2], inc.shape[1], inc.shape[0], _ptr(total),
                       _stream(inc))
         gathered = []
-        _timed(stats, lambda: gathered.extend(_all_gather(total, world, group)), total.device)
+        _timed(stats, lambda: gathered.extend(comm.all_gather(total) if comm is not None else _all_gather(total, world, group)),
+               total.device)
         totals = gathered
     else:
         totals = None
@@ -387,15 +396,19 @@ def process_pieces(par, source, length: int, piece_frames: int, sink=None, filt=
 
     if world > 1:
         tail_in = torch.empty_like(held) if prev_tail else None
-        _timed(stats, lambda: _neighbour_exchange(tail if sp.tail else None, tail_in, rank, group), carried.device)
+        _timed(stats, lambda: (comm.neighbour_exchange(tail if sp.tail else None, tail_in) if comm is not None else
+                               _neighbour_exchange(tail if sp.tail else None, tail_in, rank, group)), carried.device)
         if tail_in is not None:
             held = tail_in + held
             if collected is not None:
                 collected.insert(0, held)
             else:
                 sink(sp.out_lo, held)
-        last = dist.get_global_rank(group, world - 1) if group else world - 1
-        _timed(stats, lambda: (dist.broadcast(carried, last, group=group), dist.broadcast(sph, last, group=group)),
-               carried.device)
+        if comm is not None:
+            _timed(stats, lambda: comm.broadcast_from_last([carried, sph]), carried.device)
+        else:
+            last = dist.get_global_rank(group, world - 1) if group else world - 1
+            _timed(stats, lambda: (dist.broadcast(carried, last, group=group), dist.broadcast(sph, last, group=group)),
+                   carried.device)
     y_all = torch.cat(collected, dim=1) if collected is not None else None
     return y_all, (carried, sph)
