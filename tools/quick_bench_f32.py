@@ -7,7 +7,9 @@ C = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 N = W = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 H = N // 4
 L = 2_880_000
-par = V.VocoderParams(N, H, Wn.hann_window(W), precision="f32")
+from vocoder_amd._ffi import Library
+lib = Library(os.environ['VOC_LIB']) if os.environ.get('VOC_LIB') else None   # development: time an experimental build
+par = V.VocoderParams(N, H, Wn.hann_window(W), precision="f32", lib=lib)
 x = torch.rand(C, L, dtype=torch.float32, device="cuda") - 0.5
 F = Cd.num_frames(par, L); n = Cd.ola_length(par, F, H)
 y = torch.empty(C, n, dtype=torch.float32, device="cuda")

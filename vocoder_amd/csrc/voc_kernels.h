@@ -55,6 +55,10 @@ struct ParamsT {
     const cplx<R> *twP;    // [M-1]    per-pass twiddles, see fft_passes
     const cplx<R> *twS;    // [M/2+1]  exp(-2 pi i k / N)
     double omega1;         // 2 pi H / N when H and N are powers of two (the scaling is then exact), else 0
+    // single-precision contexts with omega1 != 0: omega1 as the sum of two floats, and N/H - 1 (bin k advances
+    // by (k mod N/H) / (N/H) of a turn per hop, modulo whole turns)
+    float om1_hi, om1_lo;
+    int turn_mask;
 };
 using Params = ParamsT<double>;
 
@@ -592,16 +596,47 @@ VOC_DEV double phase_inc_pow2(const ParamsT<double> &p, int k, double ph_diff)
     return (omega + hs_wrap(ph_diff - omega)) * p.inv_hop;
 }
 
-VOC_DEV float phase_inc_pow2(const ParamsT<float> &p, int k, float ph_diff)
+// ---- the single-precision variant's phase arithmetic, on the 32-bit units.
+// A float has a resolution of 2.4e-4 rad at the few thousand radians omega reaches, so the two places where
+// such a quantity meets one of a few radians keep omega as the sum of two floats and reduce by whole turns with
+// a two-word 2 pi (the earlier form widened both to double: the same values to within the float rounding of the
+// result, at twice the issue cost per instruction).
+constexpr float kTwoPiHiF = 6.28318548202514648f;      // float(2 pi)
+constexpr float kTwoPiLoF = -1.74845553146951715e-7f;  // 2 pi - float(2 pi)
+constexpr float kInvTwoPiF = 0.159154943091895336f;
+constexpr float kPiF = 3.14159274101257324f;
+
+// x minus the nearest whole number of turns: in [-pi, pi] to within an ulp, for |x| up to about 2^20
+VOC_DEV float wrap_near_f(float x)
 {
-    const double omega = (double)k * p.omega1;
-    return (float)((omega + hs_wrap((double)ph_diff - omega)) * (double)p.inv_hop);
+    const float n = rintf(x * kInvTwoPiF);
+    return fmaf(-n, kTwoPiLoF, fmaf(-n, kTwoPiHiF, x));
 }
 
-// float variant: omega reaches thousands of radians, so the sum is formed in double (a float
-// 2 pi alone would bias every frame's increment by omega * 3e-8) and rounded to float once.
+// x of a few turns at most into [-pi, pi) (floored, like the reference's wrap)
+VOC_DEV float wrap_floor_f(float x)
+{
+    const float n = floorf((x + kPiF) * kInvTwoPiF);
+    return fmaf(-n, kTwoPiLoF, fmaf(-n, kTwoPiHiF, x));
+}
+
+// calcPhaseInc for H and N powers of two: omega = k omega1 as two floats (the product's rounding error is
+// recovered by an fma), its whole turns dropped before it meets the phase difference
+VOC_DEV float phase_inc_pow2(const ParamsT<float> &p, int k, float ph_diff)
+{
+    const float kf = (float)k, km = (float)(k & p.turn_mask);
+    const float w = wrap_floor_f(ph_diff - km * p.om1_hi);            // (k mod N/H) omega1 < 2 pi
+    const float om_hi = kf * p.om1_hi;
+    const float om_lo = fmaf(kf, p.om1_lo, fmaf(kf, p.om1_hi, -om_hi));
+    return (om_hi + (w + om_lo)) * p.inv_hop;
+}
+
+// any other hop: omega and the sum are formed in double (a float 2 pi alone would bias every frame's increment
+// by omega * 3e-8) and rounded to float once.
 VOC_DEV float phase_inc(const ParamsT<float> &p, int k, float ph_diff)
 {
+    if (p.omega1 != 0.0) return phase_inc_pow2(p, k, ph_diff);        // (one arithmetic per context, whichever kernel runs)
+    asm volatile("");
     const double omega = bin_omega(p, k);
     const double s = omega + hs_wrap((double)ph_diff - omega);
     return (float)(p.hop_pow2 ? s * (double)p.inv_hop : s / (double)p.hop_d);
@@ -624,9 +659,9 @@ VOC_DEV void analyze_bin(const ParamsT<R> &p, int k, cplx<R> X, R &prev, bool em
 // wrapped -- in double.  The float variant wraps the sum into [-pi, pi): an unwrapped float phase
 // grows past 2^24 ulp-of-a-radian within a few thousand frames and would lose the phase entirely.
 VOC_DEV double phase_step(double ph, double t) { return ph + t; }
-// (the sum and its wrap are formed in double: t = ph_inc * H reaches thousands of radians, where a
-// float has a resolution of a milliradian)
-VOC_DEV float phase_step(float ph, float t) { return (float)hs_wrap((double)ph + (double)t); }
+// (t = ph_inc * H reaches thousands of radians, where a float has a resolution of a quarter of a milliradian:
+// its whole turns are dropped first, with a two-word 2 pi, and only then does it meet the wrapped phase)
+VOC_DEV float phase_step(float ph, float t) { return wrap_floor_f(ph + wrap_near_f(t)); }
 
 // synthesisStep for one bin (Vocoder.hs:186-190): the phase step, then mkPolar.
 template <class R, bool LEAN = false>

@@ -1455,6 +1455,9 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
             voc::ParamsT<float> &q = c->params_f;
             q.N = N; q.W = W; q.H = H; q.K = c->K; q.M = c->M;
             q.hd = p.hd; q.off = p.off; q.hop_pow2 = p.hop_pow2; q.omega1 = p.omega1;
+            q.om1_hi = (float)p.omega1;
+            q.om1_lo = (float)(p.omega1 - (double)q.om1_hi);
+            q.turn_mask = (p.omega1 != 0.0 && N >= H) ? N / H - 1 : 0;   // H <= N here: both powers of two
             q.hop_d = (float)H;
             q.inv_hop = 1.0f / (float)H;
             q.inv_n = 1.0f / (float)N;
