@@ -42,6 +42,10 @@
 #define VOC_SYN_TW_LDS 0  // synthesis: twiddle rows of the passes at stride 8 and 64 read from LDS instead of formed by multiplication
 #endif
 
+#ifndef VOC_SYN_SINCOS_TAB
+#define VOC_SYN_SINCOS_TAB 0  // (measured: 98 vector instructions per thread and frame fewer, synthesis unchanged at 27.0 ms; left off) two-wave synthesis: sine and cosine from a 64-step table of the circle in LDS (the area the register-held phases left free) and short series
+#endif
+
 #ifndef VOC_SYN_PHASE_REGS
 #define VOC_SYN_PHASE_REGS 1  // synthesis: accumulated phases in registers instead of LDS where the row prefetch is off
 #endif
@@ -914,6 +918,12 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, (syn_fat<LOG2M, OLA, R>() ?
         for (int i = tid; i < 56 + 448; i += T) twl[i] = i < 56 ? p.twP[7 + i] : p.twP[63 + (i - 56)];
         __syncthreads();
     }
+    // ... or the table of the circle, sixteen copies side by side (fast_sincos_tab): 64 x 16 x 16 bytes
+    constexpr bool SC_TAB = VOC_SYN_SINCOS_TAB != 0 && SFAT && !TW_LDS && FastCfg<LOG2M>::K * 8 >= 16384;
+    if constexpr (SC_TAB) {
+        for (int i = tid; i < 1024; i += T) twl[i] = p.cs64[i >> 4];
+        __syncthreads();
+    }
     C2 tail[NT];  // overlap-add partial sums that later frames still add to
 #pragma unroll
     for (int j = 0; j < NT; ++j) tail[j] = mk2((R)0, (R)0);
@@ -988,6 +998,10 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, (syn_fat<LOG2M, OLA, R>() ?
                 fast_sincos<LEAN>(phr[2 * m], &sa, &ca);
                 A = mk2((R)0, (R)0);
                 B = synthesize_bin<R, LEAN>(p, mg[2 * m + 1], ic[2 * m + 1], phr[2 * m + 1]);
+            } else if constexpr (SC_TAB) {
+                const C2 *col = twl + (lt & 15);
+                A = synthesize_bin_tab(p, mg[2 * m], ic[2 * m], phr[2 * m], col);
+                B = synthesize_bin_tab(p, mg[2 * m + 1], ic[2 * m + 1], phr[2 * m + 1], col);
             } else if constexpr (PHASE_REGS) {
                 A = synthesize_bin<R, LEAN>(p, mg[2 * m], ic[2 * m], phr[2 * m]);
                 B = synthesize_bin<R, LEAN>(p, mg[2 * m + 1], ic[2 * m + 1], phr[2 * m + 1]);

@@ -63,7 +63,7 @@ struct voc_ctx {
     std::vector<double> window;
     double vol = 0.0;
     double *d_window = nullptr;
-    double2 *d_twP = nullptr, *d_twS = nullptr;
+    double2 *d_twP = nullptr, *d_twS = nullptr, *d_cs64 = nullptr;
     voc::Params params{};
     int precision = VOC_PRECISION_F64;
     // frame lengths that are not powers of two: chirp-z transform over an L-point FFT (M and log2m
@@ -1354,6 +1354,15 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
         HIPCHK(hipMemcpy(c->d_window, win2.data(), sizeof(double) * win2.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->d_twP, twP.data(), sizeof(double2) * twP.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->d_twS, twS.data(), sizeof(double2) * twS.size(), hipMemcpyHostToDevice));
+        {   // the circle in 64 steps (fast_sincos_tab); the multiples of a quarter turn are exact
+            std::vector<double2> cs64(64);
+            for (int j = 0; j < 64; ++j) {
+                const long double ang = two_pi * (long double)j / 64.0L;
+                cs64[j] = make_double2(j % 32 == 16 ? 0.0 : (double)cosl(ang), j % 32 == 0 ? 0.0 : (double)sinl(ang));
+            }
+            HIPCHK(hipMalloc((void **)&c->d_cs64, sizeof(double2) * cs64.size()));
+            HIPCHK(hipMemcpy(c->d_cs64, cs64.data(), sizeof(double2) * cs64.size(), hipMemcpyHostToDevice));
+        }
 
         voc::Params &p = c->params;
         p.N = N; p.W = W; p.H = H; p.K = c->K; p.M = c->M;
@@ -1369,6 +1378,7 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
         p.window_n = c->d_window + W;
         p.twP = c->d_twP;
         p.twS = c->d_twS;
+        p.cs64 = c->d_cs64;
         if (chirp) {
             const int L = chirp_len;
             const long double pi_l = 3.141592653589793238462643383279502884L;
@@ -1486,6 +1496,7 @@ VOC_EXPORT int32_t voc_ctx_destroy(voc_ctx *c)
     if (c->d_window) (void)hipFree(c->d_window);
     if (c->d_twP) (void)hipFree(c->d_twP);
     if (c->d_twS) (void)hipFree(c->d_twS);
+    if (c->d_cs64) (void)hipFree(c->d_cs64);
     if (c->d_chirp) (void)hipFree(c->d_chirp);
     if (c->d_bfft) (void)hipFree(c->d_bfft);
     if (c->d_wl) (void)hipFree(c->d_wl);
