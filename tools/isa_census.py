@@ -1,7 +1,7 @@
 """Register / LDS / occupancy figures and a static instruction census of the hot kernels, from the compiler's
 own output.  Builds the N = 4096 kernels only (seconds), keeps nothing but two small text files.
 
-usage: python tools/isa_census.py [out_dir]      (default: profiles/, files r02_resource_usage.txt, r02_isa_census.txt)
+usage: python tools/isa_census.py [out_dir]      (default: profiles/, files r03_resource_usage.txt, r03_isa_census.txt)
 """
 import collections
 import os
@@ -11,7 +11,8 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HOT = ("analysis_fast_kernelILi11ELb1ELi2EdE", "synthesis_fast_kernelILi11ELb1ELi2EdLb0EE", "phase_carry_kernelIdE")
+HOT = ("analysis_fast16_kernelILi11ELb1ELi4EdE", "synthesis_fast_kernelILi11ELb1ELi2EdLb0EE", "analysis_fast_kernelILi11ELb1ELi2EdE",
+       "synthesis_fast16_kernelILi11ELi4EdLb0EE", "phase_carry_kernelIdE")
 
 
 def classify(op):
@@ -51,10 +52,11 @@ def main():
         text = open(asm).read()
     # ---- resource usage: the remark block of each hot kernel
     blocks = re.split(r"(?=remark: [^\n]*Function Name:)", remarks)
-    with open(os.path.join(out_dir, "r02_resource_usage.txt"), "w") as f:
+    with open(os.path.join(out_dir, "r03_resource_usage.txt"), "w") as f:
         f.write("# hipcc -Rpass-analysis=kernel-resource-usage, gfx950, N = 4096 kernels of the metric configuration.\n"
-                "# LDS is sized at launch (dynamic): 49 168 B per workgroup of 256 threads (FFT area + phase area).\n"
-                "# Analysis runs 3 workgroups (12 waves) per CU; synthesis is built for 2 waves per SIMD (2 workgroups per CU).\n")
+                "# LDS is sized at launch (dynamic).  The kernels of the metric path: analysis_fast16 (sixteen points per thread: 32 768 B per\n"
+                "# workgroup of 128 threads, 4 workgroups = 8 waves per CU) and synthesis_fast (eight points per thread: 49 168 B per workgroup\n"
+                "# of 256 threads, built for 2 waves per SIMD = 2 workgroups per CU).  The other two are the alternatives they were measured against.\n")
         for b in blocks:
             if any(h in b for h in HOT):
                 for line in b.splitlines():
@@ -63,7 +65,7 @@ def main():
                         f.write(line.rstrip() + "\n")
                 f.write("\n")
     # ---- static instruction census per hot kernel
-    with open(os.path.join(out_dir, "r02_isa_census.txt"), "w") as f:
+    with open(os.path.join(out_dir, "r03_isa_census.txt"), "w") as f:
         f.write("# Static count of the instructions in the code object of each hot kernel (every instruction once,\n"
                 "# whatever loop it sits in; the per-frame loop with its unrolled bin loop is most of each kernel).\n")
         for h in HOT:
@@ -101,8 +103,8 @@ def main():
                     f.write(f"  {k:50s} {v:6d}  {100.0 * v / total:5.1f} %\n")
                 f.write(f"  {'total':50s} {total:6d}\n")
                 f.write("  most frequent: " + ", ".join(f"{o} {n}" for o, n in ops.most_common(16)) + "\n")
-    print(open(os.path.join(out_dir, "r02_resource_usage.txt")).read())
-    print(open(os.path.join(out_dir, "r02_isa_census.txt")).read())
+    print(open(os.path.join(out_dir, "r03_resource_usage.txt")).read())
+    print(open(os.path.join(out_dir, "r03_isa_census.txt")).read())
 
 
 if __name__ == "__main__":
