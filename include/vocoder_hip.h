@@ -446,6 +446,20 @@ int32_t voc_stream_flush_dev(voc_stream *s, double *y, int64_t y_stride, int64_t
  * (float samples, STFT and phases; the synthesis phase kept wrapped), to that variant's own bar. */
 int32_t voc_analysis_stage_f32(voc_ctx *ctx, float *phase_io, const float *frames, float *mag, float *ph_inc,
                                int64_t channels, int64_t nframes);
+/* ... and the FFT-compatible layer, the step level and addFrames (voc_r2c, voc_c2r, voc_do_fft, voc_do_ifft,
+ * voc_analysis_step, voc_synthesis_step, voc_add_frames: Vocoder.hs:143-145,194-196,158-163,186-190,220-222) on
+ * float data, for contexts created with VOC_PRECISION_F32: same arguments, every array float (a complex
+ * element is two floats, {re, im}); synthesis_step returns its phases wrapped, like every form of the variant. */
+int32_t voc_r2c_f32(voc_ctx *ctx, const float *in, float *out, int64_t batch);
+int32_t voc_c2r_f32(voc_ctx *ctx, const float *in, float *out, int64_t batch);
+int32_t voc_do_fft_f32(voc_ctx *ctx, const float *frames, float *spec, int64_t batch);
+int32_t voc_do_ifft_f32(voc_ctx *ctx, const float *spec, float *frames, int64_t batch);
+int32_t voc_analysis_step_f32(voc_ctx *ctx, const float *prev_ph, const float *spec, float *ph_out, float *mag,
+                              float *ph_inc, int64_t batch);
+int32_t voc_synthesis_step_f32(voc_ctx *ctx, const float *ph, const float *mag, const float *ph_inc, float *ph_out,
+                               float *spec, int64_t batch);
+int32_t voc_add_frames_f32(voc_ctx *ctx, const float *mag1, const float *inc1, const float *mag2, const float *inc2,
+                           float *mag_out, float *inc_out, int64_t batch);
 int32_t voc_synthesis_stage_f32(voc_ctx *ctx, float *phase_io, const float *mag, const float *ph_inc, float *frames,
                                 int64_t channels, int64_t nframes);
 int32_t voc_analysis_stage_f32_dev(voc_ctx *ctx, float *phase_io, const float *frames, float *mag, float *ph_inc,

@@ -35,9 +35,9 @@ def test_precisions_do_not_mix(emu_lib):
     p32 = V.VocoderParams(64, 16, _hann(64), lib=emu_lib, precision="f32")
     p64 = V.VocoderParams(64, 16, _hann(64), lib=emu_lib)
     x = np.zeros((1, 200))
-    with pytest.raises(V.VocoderError) as e:
-        V.do_fft(p32, np.zeros(64))                       # the FFT-compatible layer is double only
-    assert e.value.status == -2
+    fr, sp = np.zeros(64), np.zeros(33, dtype=np.complex128)
+    assert emu_lib.dll.voc_do_fft(p32.handle, fr.ctypes.data, sp.ctypes.data, 1) == -2     # double form, float context
+    assert emu_lib.dll.voc_do_fft_f32(p64.handle, fr.ctypes.data, sp.ctypes.data, 1) == -2
     ph = np.zeros(33)
     assert emu_lib.dll.voc_analysis_stage(p32.handle, ph.ctypes.data, x.ctypes.data, x.ctypes.data, x.ctypes.data, 1, 1) == -2
     assert emu_lib.dll.voc_analysis_stage_f32(p64.handle, ph.ctypes.data, x.ctypes.data, x.ctypes.data, x.ctypes.data, 1, 1) == -2
@@ -142,3 +142,58 @@ def test_f32_stream_equals_the_f32_batch_path(emu_lib, dunai):
     sf = S.Stream(par, 2, filt=filt)
     yf = np.concatenate([sf.push(x[:, :333]), sf.push(x[:, 333:]), sf.flush()], axis=1)
     assert np.array_equal(yf, yf_ref)
+
+
+@pytest.mark.parametrize("n,w,hop", [(256, 256, 64), (64, 48, 16), (1024, 1024, 256)])
+def test_f32_fft_layer_steps_and_add_frames(emu_lib, orc, n, w, hop):
+    """The FFT-compatible layer, the step level and addFrames on float data (voc_r2c_f32 ... voc_add_frames_f32)
+    against the double-precision oracle, to the float variant's accuracy."""
+    from vocoder_amd import vocoder as V
+    win = _hann(w)
+    p32 = V.VocoderParams(n, hop, win, lib=emu_lib, precision="f32")
+    k = p32.K
+    rng = np.random.default_rng(n + hop)
+    x = rng.standard_normal((3, n)).astype(np.float32)
+    spec = V.fft_execute_r2c(p32, x)
+    assert spec.dtype == np.complex64
+    ref = np.stack([orc.fft_r2c(r.astype(np.float64)) for r in x])
+    assert np.linalg.norm(spec - ref) / np.linalg.norm(ref) <= 2e-6
+    back = V.fft_execute_c2r(p32, spec)
+    assert back.dtype == np.float32 and np.abs(back - x).max() <= 2e-5
+    fr = rng.standard_normal((3, w)).astype(np.float32)
+    s2 = V.do_fft(p32, fr)
+    ref2 = np.stack([orc.do_fft(n, win, f.astype(np.float64)) for f in fr])
+    assert np.linalg.norm(s2 - ref2) / np.linalg.norm(ref2) <= 2e-6
+    f2 = V.do_ifft(p32, s2)
+    reff = np.stack([orc.do_ifft(n, win, s.astype(np.complex128)) for s in s2])
+    assert np.linalg.norm(f2 - reff) / np.linalg.norm(reff) <= 2e-6
+    prev = rng.uniform(-3, 3, (3, k)).astype(np.float32)
+    ph, (mag, inc) = V.analysis_step(p32, prev, s2)
+    assert ph.dtype == np.float32
+    for b in range(3):
+        rp, rm, ri = orc.analysis_step(hop, n, prev[b].astype(np.float64), s2[b].astype(np.complex128))
+        assert np.abs(mag[b] - rm).max() <= 1e-6 * rm.max()
+        big = rm >= 1e-3 * rm.max()
+        d = np.abs(ph[b] - rp) % (2 * np.pi)
+        assert np.minimum(d, 2 * np.pi - d)[big].max() <= 1e-4
+        # the per-hop advance: a float increment carries 6e-8 of a value of up to a few thousand radians
+        d = np.abs(inc[b].astype(np.float64) * hop - ri * hop) % (2 * np.pi)
+        assert np.minimum(d, 2 * np.pi - d)[big].max() <= 1e-3
+    nph, sp = V.synthesis_step(p32, prev, (mag, inc))
+    assert np.abs(nph).max() <= np.pi + 1e-6 and sp.dtype == np.complex64
+    for b in range(3):
+        rp, rs = orc.synthesis_step(hop, prev[b].astype(np.float64), mag[b].astype(np.float64), inc[b].astype(np.float64))
+        d = np.abs(nph[b] - rp) % (2 * np.pi)
+        assert np.minimum(d, 2 * np.pi - d).max() <= 1e-3
+        assert np.linalg.norm(sp[b] - rs) / np.linalg.norm(rs) <= 1e-3
+    m2, i2 = V.add_frames(p32, (mag, prev), (mag[::-1].copy(), prev[::-1].copy()))
+    for b in range(3):
+        rm, ri = orc.add_frames(mag[b].astype(np.float64), prev[b].astype(np.float64), mag[2 - b].astype(np.float64),
+                                prev[2 - b].astype(np.float64))
+        assert np.linalg.norm(m2[b] - rm) / np.linalg.norm(rm) <= 1e-5
+    # a double-precision context refuses the float forms and the other way round
+    p64 = V.VocoderParams(n, hop, win, lib=emu_lib)
+    assert emu_lib.dll.voc_r2c_f32(p64.handle, x.ctypes.data, spec.ctypes.data, 1) == -2
+    assert emu_lib.dll.voc_r2c(p32.handle, x.ctypes.data, spec.ctypes.data, 1) == -2
+    p32.close()
+    p64.close()

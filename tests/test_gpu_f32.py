@@ -91,3 +91,58 @@ def test_f32_stage_signal_filter_and_stream_forms_on_device(gpu_lib, orc, n, w, 
     ref = Cd.process_filter_dev(p64, (Fl.lowpass_brickwall(6000.0) >> Fl.play_speed(2)).bind(p64, 48000.0 / n),
                                 torch.from_numpy(x32.astype(np.float64)).cuda())[0].cpu().numpy()
     assert np.linalg.norm(yf - ref) <= TOL_F32_L2 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("n,w,hop", [(256, 256, 64), (64, 48, 16), (1024, 1024, 256)])
+def test_f32_fft_layer_steps_and_add_frames(gpu_lib, orc, n, w, hop):
+    """The FFT-compatible layer, the step level and addFrames on float data (voc_r2c_f32 ... voc_add_frames_f32)
+    against the double-precision oracle, to the float variant's accuracy."""
+    from vocoder_amd import vocoder as V
+    win = _hann(w)
+    p32 = V.VocoderParams(n, hop, win, lib=gpu_lib, precision="f32")
+    k = p32.K
+    rng = np.random.default_rng(n + hop)
+    x = rng.standard_normal((3, n)).astype(np.float32)
+    spec = V.fft_execute_r2c(p32, x)
+    assert spec.dtype == np.complex64
+    ref = np.stack([orc.fft_r2c(r.astype(np.float64)) for r in x])
+    assert np.linalg.norm(spec - ref) / np.linalg.norm(ref) <= 2e-6
+    back = V.fft_execute_c2r(p32, spec)
+    assert back.dtype == np.float32 and np.abs(back - x).max() <= 2e-5
+    fr = rng.standard_normal((3, w)).astype(np.float32)
+    s2 = V.do_fft(p32, fr)
+    ref2 = np.stack([orc.do_fft(n, win, f.astype(np.float64)) for f in fr])
+    assert np.linalg.norm(s2 - ref2) / np.linalg.norm(ref2) <= 2e-6
+    f2 = V.do_ifft(p32, s2)
+    reff = np.stack([orc.do_ifft(n, win, s.astype(np.complex128)) for s in s2])
+    assert np.linalg.norm(f2 - reff) / np.linalg.norm(reff) <= 2e-6
+    prev = rng.uniform(-3, 3, (3, k)).astype(np.float32)
+    ph, (mag, inc) = V.analysis_step(p32, prev, s2)
+    assert ph.dtype == np.float32
+    for b in range(3):
+        rp, rm, ri = orc.analysis_step(hop, n, prev[b].astype(np.float64), s2[b].astype(np.complex128))
+        assert np.abs(mag[b] - rm).max() <= 1e-6 * rm.max()
+        big = rm >= 1e-3 * rm.max()
+        d = np.abs(ph[b] - rp) % (2 * np.pi)
+        assert np.minimum(d, 2 * np.pi - d)[big].max() <= 1e-4
+        # the per-hop advance: a float increment carries 6e-8 of a value of up to a few thousand radians
+        d = np.abs(inc[b].astype(np.float64) * hop - ri * hop) % (2 * np.pi)
+        assert np.minimum(d, 2 * np.pi - d)[big].max() <= 1e-3
+    nph, sp = V.synthesis_step(p32, prev, (mag, inc))
+    assert np.abs(nph).max() <= np.pi + 1e-6 and sp.dtype == np.complex64
+    for b in range(3):
+        rp, rs = orc.synthesis_step(hop, prev[b].astype(np.float64), mag[b].astype(np.float64), inc[b].astype(np.float64))
+        d = np.abs(nph[b] - rp) % (2 * np.pi)
+        assert np.minimum(d, 2 * np.pi - d).max() <= 1e-3
+        assert np.linalg.norm(sp[b] - rs) / np.linalg.norm(rs) <= 1e-3
+    m2, i2 = V.add_frames(p32, (mag, prev), (mag[::-1].copy(), prev[::-1].copy()))
+    for b in range(3):
+        rm, ri = orc.add_frames(mag[b].astype(np.float64), prev[b].astype(np.float64), mag[2 - b].astype(np.float64),
+                                prev[2 - b].astype(np.float64))
+        assert np.linalg.norm(m2[b] - rm) / np.linalg.norm(rm) <= 1e-5
+    # a double-precision context refuses the float forms and the other way round
+    p64 = V.VocoderParams(n, hop, win, lib=gpu_lib)
+    assert gpu_lib.dll.voc_r2c_f32(p64.handle, x.ctypes.data, spec.ctypes.data, 1) == -2
+    assert gpu_lib.dll.voc_r2c(p32.handle, x.ctypes.data, spec.ctypes.data, 1) == -2
+    p32.close()
+    p64.close()

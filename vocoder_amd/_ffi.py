@@ -58,6 +58,13 @@ SIGNATURES = {
     "voc_synthesis_mapped_f32_dev": (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _vp]),
     "voc_analysis_signal_f32_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
     "voc_synthesis_signal_f32_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _vp]),
+    "voc_r2c_f32": (_i32, [_vp, _vp, _vp, _i64]),
+    "voc_c2r_f32": (_i32, [_vp, _vp, _vp, _i64]),
+    "voc_do_fft_f32": (_i32, [_vp, _vp, _vp, _i64]),
+    "voc_do_ifft_f32": (_i32, [_vp, _vp, _vp, _i64]),
+    "voc_analysis_step_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64]),
+    "voc_synthesis_step_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64]),
+    "voc_add_frames_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64]),
     "voc_analysis_stage_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64]),
     "voc_synthesis_stage_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64]),
     "voc_analysis_stage_f32_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),

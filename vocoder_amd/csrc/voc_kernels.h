@@ -1214,13 +1214,13 @@ __global__ void planar_to_pcm16_kernel(const double *__restrict__ planar, long l
 // ------------------------------------------------------------------ step-level, framing, overlap-add
 
 // analysisStep over B independent frames (Vocoder.hs:158-163)
-__global__ void analysis_step_kernel(Params p, const double *prev_ph, const double *spec, double *ph_out, double *mag,
-                                     double *inc, long long total)
+template <class R = double>
+__global__ void analysis_step_kernel(ParamsT<R> p, const R *prev_ph, const R *spec, R *ph_out, R *mag, R *inc, long long total)
 {
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
         const int k = (int)(g % p.K);
-        double prev = prev_ph[g], mg, ic;
-        analyze_bin<double>(p, k, make_double2(spec[2 * g], spec[2 * g + 1]), prev, true, 1.0, &mg, &ic);
+        R prev = prev_ph[g], mg, ic;
+        analyze_bin<R>(p, k, mk2(spec[2 * g], spec[2 * g + 1]), prev, true, (R)1, &mg, &ic);
         mag[g] = mg;
         inc[g] = ic;
         ph_out[g] = prev;
@@ -1228,12 +1228,12 @@ __global__ void analysis_step_kernel(Params p, const double *prev_ph, const doub
 }
 
 // synthesisStep over B independent frames (Vocoder.hs:186-190)
-__global__ void synthesis_step_kernel(Params p, const double *ph, const double *mag, const double *inc, double *ph_out,
-                                      double *spec, long long total)
+template <class R = double>
+__global__ void synthesis_step_kernel(ParamsT<R> p, const R *ph, const R *mag, const R *inc, R *ph_out, R *spec, long long total)
 {
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
-        double cur = ph[g];
-        const double2 X = synthesize_bin(p, mag[g], inc[g], cur);
+        R cur = ph[g];
+        const cplx<R> X = synthesize_bin(p, mag[g], inc[g], cur);
         spec[2 * g] = X.x;
         spec[2 * g + 1] = X.y;
         ph_out[g] = cur;
@@ -1241,15 +1241,15 @@ __global__ void synthesis_step_kernel(Params p, const double *ph, const double *
 }
 
 // addFrames (Vocoder.hs:220-222): polar -> complex, add, complex -> polar
-__global__ void add_frames_kernel(const double *mag1, const double *inc1, const double *mag2, const double *inc2,
-                                  double *mag_out, double *inc_out, long long total)
+template <class R = double>
+__global__ void add_frames_kernel(const R *mag1, const R *inc1, const R *mag2, const R *inc2, R *mag_out, R *inc_out, long long total)
 {
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
-        double s1, c1, s2, c2;
+        R s1, c1, s2, c2;
         fast_sincos(inc1[g], &s1, &c1);
         fast_sincos(inc2[g], &s2, &c2);
-        const double re = mag1[g] * c1 + mag2[g] * c2;
-        const double im = mag1[g] * s1 + mag2[g] * s2;
+        const R re = mag1[g] * c1 + mag2[g] * c2;
+        const R im = mag1[g] * s1 + mag2[g] * s2;
         hs_polar(re, im, mag_out[g], inc_out[g]);
     }
 }

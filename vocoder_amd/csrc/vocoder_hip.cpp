@@ -1531,57 +1531,136 @@ VOC_EXPORT int64_t voc_ola_length(const voc_ctx *c, int64_t F, int64_t chunk)
 // ---- FFT-compatible layer ---------------------------------------------------------------------------
 
 namespace {
-template <bool RAW>
-int32_t spec_forward(voc_ctx *c, const double *in, double *out, int64_t B)
+template <class R> constexpr int precision_of() { return std::is_same<R, float>::value ? VOC_PRECISION_F32 : VOC_PRECISION_F64; }
+
+template <bool RAW, class R = double>
+int32_t spec_forward(voc_ctx *c, const R *in, R *out, int64_t B)
 {
     if (!c || B < 0 || (B > 0 && (!in || !out))) return VOC_ERR_INVALID;
     if (B == 0) return VOC_OK;
     return guarded(c, [&]() -> int32_t {
-        Locked lk(c);
+        Locked lk(c, precision_of<R>());
         const size_t in_len = RAW ? (size_t)c->N : (size_t)c->W;
         HostCall h(c->staging, nullptr);
-        const int din = h.add((size_t)B * in_len * sizeof(double)), dout = h.add((size_t)B * c->K * 2 * sizeof(double));
+        const int din = h.add((size_t)B * in_len * sizeof(R)), dout = h.add((size_t)B * c->K * 2 * sizeof(R));
         h.commit();
         h.upload(din, in);
         h.uploads_done();
-        voc::AnaArgs a{};
-        a.x = h.dev(din);
+        voc::AnaArgsT<R> a{};
+        a.x = h.dev<R>(din);
         a.chan_stride = 0;
         a.frame_stride = (long long)in_len;
-        a.spec = h.dev(dout);
+        a.spec = h.dev<R>(dout);
         a.F = B;
         a.rpc = B;
         a.tile_len = 4;
         a.tiles = (int)((B + 3) / 4);
-        a.vol = 1.0;
-        launch_analysis<RAW, true>(c, a, 1, nullptr);
+        a.vol = (R)1;
+        launch_analysis<RAW, true, R>(c, a, 1, nullptr);
         h.download(dout, out);
         h.finish();
         return VOC_OK;
     });
 }
 
-template <int OUT_MODE>
-int32_t spec_backward(voc_ctx *c, const double *in, double *out, int64_t B)
+template <int OUT_MODE, class R = double>
+int32_t spec_backward(voc_ctx *c, const R *in, R *out, int64_t B)
 {
     if (!c || B < 0 || (B > 0 && (!in || !out))) return VOC_ERR_INVALID;
     if (B == 0) return VOC_OK;
     return guarded(c, [&]() -> int32_t {
-        Locked lk(c);
+        Locked lk(c, precision_of<R>());
         const size_t out_len = OUT_MODE == voc::SYN_OUT_RAW ? (size_t)c->N : (size_t)c->W;
         HostCall h(c->staging, nullptr);
-        const int din = h.add((size_t)B * c->K * 2 * sizeof(double)), dout = h.add((size_t)B * out_len * sizeof(double));
+        const int din = h.add((size_t)B * c->K * 2 * sizeof(R)), dout = h.add((size_t)B * out_len * sizeof(R));
         h.commit();
         h.upload(din, in);
         h.uploads_done();
-        voc::SynArgs a{};
-        a.spec = h.dev(din);
-        a.out = h.dev(dout);
+        voc::SynArgsT<R> a{};
+        a.spec = h.dev<R>(din);
+        a.out = h.dev<R>(dout);
         a.F = B;
         a.tile_len = 4;
         a.tiles = (int)((B + 3) / 4);
-        launch_synthesis<voc::SYN_IN_SPEC, OUT_MODE>(c, a, 1, nullptr);
+        launch_synthesis<voc::SYN_IN_SPEC, OUT_MODE, R>(c, a, 1, nullptr);
         h.download(dout, out);
+        h.finish();
+        return VOC_OK;
+    });
+}
+
+// analysisStep / synthesisStep / addFrames on B frames of a context, host arrays
+template <class R>
+int32_t analysis_step_host(voc_ctx *c, const R *prev_ph, const R *spec, R *ph_out, R *mag, R *ph_inc, int64_t B)
+{
+    if (!c || B < 0 || (B > 0 && (!prev_ph || !spec || !ph_out || !mag || !ph_inc))) return VOC_ERR_INVALID;
+    if (B == 0) return VOC_OK;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c, precision_of<R>());
+        const size_t n = (size_t)B * c->K, nb = n * sizeof(R);
+        HostCall h(c->staging, nullptr);
+        const int dprev = h.add(nb), dspec = h.add(2 * nb), dph = h.add(nb), dmag = h.add(nb), dinc = h.add(nb);
+        h.commit();
+        h.upload(dprev, prev_ph);
+        h.upload(dspec, spec);
+        h.uploads_done();
+        hipLaunchKernelGGL(voc::analysis_step_kernel<R>, dim3(ew_grid((long long)n)), dim3(256), 0, nullptr, params_of<R>(c),
+                           h.dev<R>(dprev), h.dev<R>(dspec), h.dev<R>(dph), h.dev<R>(dmag), h.dev<R>(dinc), (long long)n);
+        HIPCHK(hipGetLastError());
+        h.download(dph, ph_out);
+        h.download(dmag, mag);
+        h.download(dinc, ph_inc);
+        h.finish();
+        return VOC_OK;
+    });
+}
+
+template <class R>
+int32_t synthesis_step_host(voc_ctx *c, const R *ph, const R *mag, const R *ph_inc, R *ph_out, R *spec, int64_t B)
+{
+    if (!c || B < 0 || (B > 0 && (!ph || !mag || !ph_inc || !ph_out || !spec))) return VOC_ERR_INVALID;
+    if (B == 0) return VOC_OK;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c, precision_of<R>());
+        const size_t n = (size_t)B * c->K, nb = n * sizeof(R);
+        HostCall h(c->staging, nullptr);
+        const int dph = h.add(nb), dmag = h.add(nb), dinc = h.add(nb), dout = h.add(nb), dspec = h.add(2 * nb);
+        h.commit();
+        h.upload(dph, ph);
+        h.upload(dmag, mag);
+        h.upload(dinc, ph_inc);
+        h.uploads_done();
+        hipLaunchKernelGGL(voc::synthesis_step_kernel<R>, dim3(ew_grid((long long)n)), dim3(256), 0, nullptr, params_of<R>(c),
+                           h.dev<R>(dph), h.dev<R>(dmag), h.dev<R>(dinc), h.dev<R>(dout), h.dev<R>(dspec), (long long)n);
+        HIPCHK(hipGetLastError());
+        h.download(dout, ph_out);
+        h.download(dspec, spec);
+        h.finish();
+        return VOC_OK;
+    });
+}
+
+template <class R>
+int32_t add_frames_host(voc_ctx *c, const R *mag1, const R *inc1, const R *mag2, const R *inc2, R *mag_out, R *inc_out, int64_t B)
+{
+    if (!c || B < 0 || (B > 0 && (!mag1 || !inc1 || !mag2 || !inc2 || !mag_out || !inc_out))) return VOC_ERR_INVALID;
+    if (B == 0) return VOC_OK;
+    return guarded(c, [&]() -> int32_t {
+        Locked lk(c, precision_of<R>());
+        const size_t n = (size_t)B * c->K, nb = n * sizeof(R);
+        HostCall h(c->staging, nullptr);
+        const int a = h.add(nb), b = h.add(nb), d = h.add(nb), e = h.add(nb), mo = h.add(nb), io = h.add(nb);
+        h.commit();
+        h.upload(a, mag1);
+        h.upload(b, inc1);
+        h.upload(d, mag2);
+        h.upload(e, inc2);
+        h.uploads_done();
+        hipLaunchKernelGGL(voc::add_frames_kernel<R>, dim3(ew_grid((long long)n)), dim3(256), 0, nullptr, h.dev<R>(a), h.dev<R>(b),
+                           h.dev<R>(d), h.dev<R>(e), h.dev<R>(mo), h.dev<R>(io), (long long)n);
+        HIPCHK(hipGetLastError());
+        h.download(mo, mag_out);
+        h.download(io, inc_out);
         h.finish();
         return VOC_OK;
     });
@@ -1592,83 +1671,44 @@ VOC_EXPORT int32_t voc_r2c(voc_ctx *c, const double *in, double *out, int64_t B)
 VOC_EXPORT int32_t voc_do_fft(voc_ctx *c, const double *fr, double *spec, int64_t B) { return spec_forward<false>(c, fr, spec, B); }
 VOC_EXPORT int32_t voc_c2r(voc_ctx *c, const double *in, double *out, int64_t B) { return spec_backward<voc::SYN_OUT_RAW>(c, in, out, B); }
 VOC_EXPORT int32_t voc_do_ifft(voc_ctx *c, const double *spec, double *fr, int64_t B) { return spec_backward<voc::SYN_OUT_FRAMES>(c, spec, fr, B); }
+VOC_EXPORT int32_t voc_r2c_f32(voc_ctx *c, const float *in, float *out, int64_t B) { return spec_forward<true, float>(c, in, out, B); }
+VOC_EXPORT int32_t voc_do_fft_f32(voc_ctx *c, const float *fr, float *spec, int64_t B) { return spec_forward<false, float>(c, fr, spec, B); }
+VOC_EXPORT int32_t voc_c2r_f32(voc_ctx *c, const float *in, float *out, int64_t B) { return spec_backward<voc::SYN_OUT_RAW, float>(c, in, out, B); }
+VOC_EXPORT int32_t voc_do_ifft_f32(voc_ctx *c, const float *spec, float *fr, int64_t B) { return spec_backward<voc::SYN_OUT_FRAMES, float>(c, spec, fr, B); }
 
 // ---- step level ---------------------------------------------------------------------------------------
 
 VOC_EXPORT int32_t voc_analysis_step(voc_ctx *c, const double *prev_ph, const double *spec, double *ph_out, double *mag,
                                      double *ph_inc, int64_t B)
 {
-    if (!c || B < 0 || (B > 0 && (!prev_ph || !spec || !ph_out || !mag || !ph_inc))) return VOC_ERR_INVALID;
-    if (B == 0) return VOC_OK;
-    return guarded(c, [&]() -> int32_t {
-        Locked lk(c);
-        const size_t n = (size_t)B * c->K, nb = n * sizeof(double);
-        HostCall h(c->staging, nullptr);
-        const int dprev = h.add(nb), dspec = h.add(2 * nb), dph = h.add(nb), dmag = h.add(nb), dinc = h.add(nb);
-        h.commit();
-        h.upload(dprev, prev_ph);
-        h.upload(dspec, spec);
-        h.uploads_done();
-        hipLaunchKernelGGL(voc::analysis_step_kernel, dim3(ew_grid((long long)n)), dim3(256), 0, nullptr, c->params,
-                           h.dev(dprev), h.dev(dspec), h.dev(dph), h.dev(dmag), h.dev(dinc), (long long)n);
-        HIPCHK(hipGetLastError());
-        h.download(dph, ph_out);
-        h.download(dmag, mag);
-        h.download(dinc, ph_inc);
-        h.finish();
-        return VOC_OK;
-    });
+    return analysis_step_host<double>(c, prev_ph, spec, ph_out, mag, ph_inc, B);
+}
+VOC_EXPORT int32_t voc_analysis_step_f32(voc_ctx *c, const float *prev_ph, const float *spec, float *ph_out, float *mag,
+                                         float *ph_inc, int64_t B)
+{
+    return analysis_step_host<float>(c, prev_ph, spec, ph_out, mag, ph_inc, B);
 }
 
 VOC_EXPORT int32_t voc_synthesis_step(voc_ctx *c, const double *ph, const double *mag, const double *ph_inc,
                                       double *ph_out, double *spec, int64_t B)
 {
-    if (!c || B < 0 || (B > 0 && (!ph || !mag || !ph_inc || !ph_out || !spec))) return VOC_ERR_INVALID;
-    if (B == 0) return VOC_OK;
-    return guarded(c, [&]() -> int32_t {
-        Locked lk(c);
-        const size_t n = (size_t)B * c->K, nb = n * sizeof(double);
-        HostCall h(c->staging, nullptr);
-        const int dph = h.add(nb), dmag = h.add(nb), dinc = h.add(nb), dout = h.add(nb), dspec = h.add(2 * nb);
-        h.commit();
-        h.upload(dph, ph);
-        h.upload(dmag, mag);
-        h.upload(dinc, ph_inc);
-        h.uploads_done();
-        hipLaunchKernelGGL(voc::synthesis_step_kernel, dim3(ew_grid((long long)n)), dim3(256), 0, nullptr, c->params,
-                           h.dev(dph), h.dev(dmag), h.dev(dinc), h.dev(dout), h.dev(dspec), (long long)n);
-        HIPCHK(hipGetLastError());
-        h.download(dout, ph_out);
-        h.download(dspec, spec);
-        h.finish();
-        return VOC_OK;
-    });
+    return synthesis_step_host<double>(c, ph, mag, ph_inc, ph_out, spec, B);
+}
+VOC_EXPORT int32_t voc_synthesis_step_f32(voc_ctx *c, const float *ph, const float *mag, const float *ph_inc,
+                                          float *ph_out, float *spec, int64_t B)
+{
+    return synthesis_step_host<float>(c, ph, mag, ph_inc, ph_out, spec, B);
 }
 
 VOC_EXPORT int32_t voc_add_frames(voc_ctx *c, const double *mag1, const double *inc1, const double *mag2,
                                   const double *inc2, double *mag_out, double *inc_out, int64_t B)
 {
-    if (!c || B < 0 || (B > 0 && (!mag1 || !inc1 || !mag2 || !inc2 || !mag_out || !inc_out))) return VOC_ERR_INVALID;
-    if (B == 0) return VOC_OK;
-    return guarded(c, [&]() -> int32_t {
-        Locked lk(c);
-        const size_t n = (size_t)B * c->K, nb = n * sizeof(double);
-        HostCall h(c->staging, nullptr);
-        const int a = h.add(nb), b = h.add(nb), d = h.add(nb), e = h.add(nb), mo = h.add(nb), io = h.add(nb);
-        h.commit();
-        h.upload(a, mag1);
-        h.upload(b, inc1);
-        h.upload(d, mag2);
-        h.upload(e, inc2);
-        h.uploads_done();
-        hipLaunchKernelGGL(voc::add_frames_kernel, dim3(ew_grid((long long)n)), dim3(256), 0, nullptr, h.dev(a), h.dev(b),
-                           h.dev(d), h.dev(e), h.dev(mo), h.dev(io), (long long)n);
-        HIPCHK(hipGetLastError());
-        h.download(mo, mag_out);
-        h.download(io, inc_out);
-        h.finish();
-        return VOC_OK;
-    });
+    return add_frames_host<double>(c, mag1, inc1, mag2, inc2, mag_out, inc_out, B);
+}
+VOC_EXPORT int32_t voc_add_frames_f32(voc_ctx *c, const float *mag1, const float *inc1, const float *mag2,
+                                      const float *inc2, float *mag_out, float *inc_out, int64_t B)
+{
+    return add_frames_host<float>(c, mag1, inc1, mag2, inc2, mag_out, inc_out, B);
 }
 
 // ---- the reference's functions that take no VocoderParams ----------------------------------------------
@@ -1734,7 +1774,7 @@ VOC_EXPORT int32_t voc_analysis_step_hn(int32_t hop, int32_t n, int64_t K, const
         h.upload(dprev, prev_ph);
         h.upload(dspec, spec);
         h.uploads_done();
-        hipLaunchKernelGGL(voc::analysis_step_kernel, dim3(ew_grid((long long)cnt)), dim3(256), 0, nullptr,
+        hipLaunchKernelGGL(voc::analysis_step_kernel<double>, dim3(ew_grid((long long)cnt)), dim3(256), 0, nullptr,
                            step_params(hop, n, K), h.dev(dprev), h.dev(dspec), h.dev(dph), h.dev(dmag), h.dev(dinc),
                            (long long)cnt);
         HIPCHK(hipGetLastError());
@@ -1762,7 +1802,7 @@ VOC_EXPORT int32_t voc_synthesis_step_h(int32_t hop, int64_t K, const double *ph
         h.upload(dmag, mag);
         h.upload(dinc, ph_inc);
         h.uploads_done();
-        hipLaunchKernelGGL(voc::synthesis_step_kernel, dim3(ew_grid((long long)cnt)), dim3(256), 0, nullptr,
+        hipLaunchKernelGGL(voc::synthesis_step_kernel<double>, dim3(ew_grid((long long)cnt)), dim3(256), 0, nullptr,
                            step_params(hop, 2, K), h.dev(dph), h.dev(dmag), h.dev(dinc), h.dev(dout), h.dev(dspec),
                            (long long)cnt);
         HIPCHK(hipGetLastError());
@@ -1833,7 +1873,7 @@ VOC_EXPORT int32_t voc_add_frames_n(const double *mag1, const double *inc1, cons
         h.upload(d, mag2);
         h.upload(e, inc2);
         h.uploads_done();
-        hipLaunchKernelGGL(voc::add_frames_kernel, dim3(ew_grid((long long)count)), dim3(256), 0, nullptr, h.dev(a),
+        hipLaunchKernelGGL(voc::add_frames_kernel<double>, dim3(ew_grid((long long)count)), dim3(256), 0, nullptr, h.dev(a),
                            h.dev(b), h.dev(d), h.dev(e), h.dev(mo), h.dev(io), (long long)count);
         HIPCHK(hipGetLastError());
         h.download(mo, mag_out);
@@ -1850,7 +1890,7 @@ VOC_EXPORT int32_t voc_add_frames_dev(voc_ctx *c, const double *mag1, const doub
     if (count == 0) return VOC_OK;
     return guarded(c, [&]() -> int32_t {
         Locked lk(c);
-        hipLaunchKernelGGL(voc::add_frames_kernel, dim3(ew_grid((long long)count)), dim3(256), 0, (hipStream_t)stream, mag1,
+        hipLaunchKernelGGL(voc::add_frames_kernel<double>, dim3(ew_grid((long long)count)), dim3(256), 0, (hipStream_t)stream, mag1,
                            inc1, mag2, inc2, mag_out, inc_out, (long long)count);
         HIPCHK(hipGetLastError());
         return VOC_OK;

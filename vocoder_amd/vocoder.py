@@ -114,6 +114,12 @@ def zero_phase(par, channels: int | None = None) -> np.ndarray:
     return np.zeros(par.K if channels is None else (channels, par.K))
 
 
+def _rc(par):
+    """(real dtype, complex dtype, entry-point suffix) of a context: single-precision contexts take float arrays
+    through the `_f32` forms of the same entry points."""
+    return (np.float32, np.complex64, "_f32") if getattr(par, "precision", "f64") == "f32" else (np.float64, np.complex128, "")
+
+
 def _batched(a, inner, dtype=np.float64):
     a = np.ascontiguousarray(a, dtype=dtype)
     if a.shape[-1] != inner:
@@ -125,33 +131,37 @@ def _batched(a, inner, dtype=np.float64):
 
 def fft_execute_r2c(par, x) -> np.ndarray:
     """`FFT.execute (plan dftR2C N)`: N reals -> K complex, unnormalised (Vocoder.hs:145)."""
-    x, lead = _batched(x, par.N)
-    out = np.empty((x.shape[0], par.K), dtype=np.complex128)
-    par._call("voc_r2c", _p(x), _p(out), x.shape[0])
+    rt, ct, sfx = _rc(par)
+    x, lead = _batched(x, par.N, rt)
+    out = np.empty((x.shape[0], par.K), dtype=ct)
+    par._call("voc_r2c" + sfx, _p(x), _p(out), x.shape[0])
     return out.reshape(lead + (par.K,))
 
 
 def fft_execute_c2r(par, spec) -> np.ndarray:
     """`FFT.execute (plan dftC2R N)`: K complex -> N reals, scaled by 1/N (Vocoder.hs:196)."""
-    spec, lead = _batched(spec, par.K, np.complex128)
-    out = np.empty((spec.shape[0], par.N))
-    par._call("voc_c2r", _p(spec), _p(out), spec.shape[0])
+    rt, ct, sfx = _rc(par)
+    spec, lead = _batched(spec, par.K, ct)
+    out = np.empty((spec.shape[0], par.N), dtype=rt)
+    par._call("voc_c2r" + sfx, _p(spec), _p(out), spec.shape[0])
     return out.reshape(lead + (par.N,))
 
 
 def do_fft(par, frame) -> np.ndarray:
     """doFFT (Vocoder.hs:143-145)."""
-    frame, lead = _batched(frame, par.W)
-    out = np.empty((frame.shape[0], par.K), dtype=np.complex128)
-    par._call("voc_do_fft", _p(frame), _p(out), frame.shape[0])
+    rt, ct, sfx = _rc(par)
+    frame, lead = _batched(frame, par.W, rt)
+    out = np.empty((frame.shape[0], par.K), dtype=ct)
+    par._call("voc_do_fft" + sfx, _p(frame), _p(out), frame.shape[0])
     return out.reshape(lead + (par.K,))
 
 
 def do_ifft(par, spec) -> np.ndarray:
     """doIFFT (Vocoder.hs:194-196)."""
-    spec, lead = _batched(spec, par.K, np.complex128)
-    out = np.empty((spec.shape[0], par.W))
-    par._call("voc_do_ifft", _p(spec), _p(out), spec.shape[0])
+    rt, ct, sfx = _rc(par)
+    spec, lead = _batched(spec, par.K, ct)
+    out = np.empty((spec.shape[0], par.W), dtype=rt)
+    par._call("voc_do_ifft" + sfx, _p(spec), _p(out), spec.shape[0])
     return out.reshape(lead + (par.W,))
 
 
@@ -168,11 +178,12 @@ def analysis_step(par_or_hop, *args, lib: Library | None = None):
     if isinstance(par_or_hop, VocoderParams):
         par = par_or_hop
         prev_ph, spec = args
-        spec, lead = _batched(spec, par.K, np.complex128)
-        prev_ph, _ = _batched(prev_ph, par.K)
+        rt, ct, sfx = _rc(par)
+        spec, lead = _batched(spec, par.K, ct)
+        prev_ph, _ = _batched(prev_ph, par.K, rt)
         b, k = spec.shape[0], par.K
-        ph, mag, inc = np.empty((b, k)), np.empty((b, k)), np.empty((b, k))
-        par._call("voc_analysis_step", _p(prev_ph), _p(spec), _p(ph), _p(mag), _p(inc), b)
+        ph, mag, inc = np.empty((b, k), dtype=rt), np.empty((b, k), dtype=rt), np.empty((b, k), dtype=rt)
+        par._call("voc_analysis_step" + sfx, _p(prev_ph), _p(spec), _p(ph), _p(mag), _p(inc), b)
     else:
         hop, n, prev_ph, spec = (par_or_hop,) + args
         spec = np.ascontiguousarray(spec, dtype=np.complex128)
@@ -190,15 +201,16 @@ def synthesis_step(par_or_hop, ph, stft, lib: Library | None = None):
     """synthesisStep hop ph (mag, ph_inc) -> (new_ph, spectrum) (Vocoder.hs:186-190).  The first
     argument is the hop size, as in the reference, or a `VocoderParams` whose hop size is used."""
     mag, inc = stft
-    mag = np.ascontiguousarray(mag, dtype=np.float64)
+    rt, ct, sfx = _rc(par_or_hop) if isinstance(par_or_hop, VocoderParams) else (np.float64, np.complex128, "")
+    mag = np.ascontiguousarray(mag, dtype=rt)
     k = par_or_hop.K if isinstance(par_or_hop, VocoderParams) else mag.shape[-1]
-    mag, lead = _batched(mag, k)
-    inc, _ = _batched(inc, k)
-    ph, _ = _batched(ph, k)
+    mag, lead = _batched(mag, k, rt)
+    inc, _ = _batched(inc, k, rt)
+    ph, _ = _batched(ph, k, rt)
     b = mag.shape[0]
-    out, spec = np.empty((b, k)), np.empty((b, k), dtype=np.complex128)
+    out, spec = np.empty((b, k), dtype=rt), np.empty((b, k), dtype=ct)
     if isinstance(par_or_hop, VocoderParams):
-        par_or_hop._call("voc_synthesis_step", _p(ph), _p(mag), _p(inc), _p(out), _p(spec), b)
+        par_or_hop._call("voc_synthesis_step" + sfx, _p(ph), _p(mag), _p(inc), _p(out), _p(spec), b)
     else:
         _free_call(lib, "voc_synthesis_step_h", int(par_or_hop), k, _p(ph), _p(mag), _p(inc), _p(out), _p(spec), b)
     sh = lead + (k,)
@@ -227,13 +239,14 @@ def add_frames(*args, lib: Library | None = None):
     """addFrames f1 f2 (Vocoder.hs:220-222); `add_frames(par, f1, f2)` is accepted too."""
     if len(args) == 3:
         par, f1, f2 = args
-        m1, lead = _batched(f1[0], par.K)
-        i1, _ = _batched(f1[1], par.K)
-        m2, _ = _batched(f2[0], par.K)
-        i2, _ = _batched(f2[1], par.K)
+        rt, _, sfx = _rc(par)
+        m1, lead = _batched(f1[0], par.K, rt)
+        i1, _ = _batched(f1[1], par.K, rt)
+        m2, _ = _batched(f2[0], par.K, rt)
+        i2, _ = _batched(f2[1], par.K, rt)
         b = m1.shape[0]
-        mo, io = np.empty((b, par.K)), np.empty((b, par.K))
-        par._call("voc_add_frames", _p(m1), _p(i1), _p(m2), _p(i2), _p(mo), _p(io), b)
+        mo, io = np.empty((b, par.K), dtype=rt), np.empty((b, par.K), dtype=rt)
+        par._call("voc_add_frames" + sfx, _p(m1), _p(i1), _p(m2), _p(i2), _p(mo), _p(io), b)
         sh = lead + (par.K,)
         return mo.reshape(sh), io.reshape(sh)
     f1, f2 = args
