@@ -197,3 +197,29 @@ def test_f32_fft_layer_steps_and_add_frames(emu_lib, orc, n, w, hop):
     assert emu_lib.dll.voc_r2c(p32.handle, x.ctypes.data, spec.ctypes.data, 1) == -2
     p32.close()
     p64.close()
+
+
+@pytest.mark.parametrize("ana16,syn16", [(0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("n,hop,nf,at,st", [(4096, 1024, 9, 0, 0), (4096, 512, 14, 4, 5), (8192, 2048, 6, 3, 3)])
+def test_f32_eight_and_sixteen_points_per_thread(emu_lib, orc, monkeypatch, n, hop, nf, at, st, ana16, syn16):
+    """Single-precision contexts take the sixteen-point analysis kernel at N >= 4096 (voc_kernels_fast16.h); every
+    combination of the two builds is held to the variant's bar against the double-precision oracle."""
+    from vocoder_amd import vocoder as V, conduit as Cd
+    monkeypatch.setenv("VOC_FAST16_F32_ANA", str(ana16))
+    monkeypatch.setenv("VOC_FAST16_F32_SYN", str(syn16))
+    if at:
+        monkeypatch.setenv("VOC_ANA_TILE_LEN", str(at))
+        monkeypatch.setenv("VOC_SYN_TILE_LEN", str(st))
+    win = _hann(n)
+    par = V.VocoderParams(n, hop, win, lib=emu_lib, precision="f32")
+    rng = np.random.default_rng(n + hop + nf)
+    c, length = 2, n + hop * (nf - 1) + 6
+    t = np.arange(length)
+    x = (np.stack([0.5 * np.sin(2 * np.pi * 0.0131 * (i + 1) * t) for i in range(c)]) + 0.01 * rng.uniform(-1, 1, (c, length))).astype(np.float32)
+    y, left, (aph, sph) = Cd.process_with(par, x)
+    for ch in range(c):
+        ref = orc.roundtrip(n, hop, win, x[ch].astype(np.float64), hop)
+        assert y.shape[1] == ref["y"].size
+        err = np.linalg.norm(y[ch] - ref["y"]) / np.linalg.norm(ref["y"])
+        assert err <= TOL_F32_L2, err
+    par.close()

@@ -17,7 +17,30 @@
 
 #include "voc_kernels_fast.h"
 
+// Single precision: a thread's state is half as many registers, so three waves per SIMD fit (168 registers each)
+// where a workgroup is at most four waves; the eight-wave workgroups of N = 16384 stay at two.
+#ifndef VOC_F32_16_WAVES
+#define VOC_F32_16_WAVES 3      // analysis
+#endif
+#ifndef VOC_F32_SYN16_WAVES
+#define VOC_F32_SYN16_WAVES 3   // synthesis
+#endif
+// Whether single-precision contexts take these kernels (VOC_FAST16_F32_ANA / VOC_FAST16_F32_SYN override):
+// analysis yes (N = 4096: 20.6 -> 19.1 ms on the metric shape); synthesis only where there is no eight-point
+// kernel (N = 16384), as in double precision.
+#ifndef VOC_FAST16_F32_ANA_DEFAULT
+#define VOC_FAST16_F32_ANA_DEFAULT 1
+#endif
+#ifndef VOC_FAST16_F32_SYN_DEFAULT
+#define VOC_FAST16_F32_SYN_DEFAULT (-1)
+#endif
+
 namespace voc {
+
+template <class R, int LOG2M> constexpr int fast16_waves(int waves_double, int waves_float)
+{
+    return sizeof(R) == 4 ? (LOG2M == 13 ? 2 : waves_float) : waves_double;
+}
 
 template <int LOG2M>
 struct Fast16Cfg {
@@ -286,7 +309,7 @@ VOC_DEV void fft16_after_first(C2 *lds, const Fast16Tw<LOG2M, C2> &t, int lt, C2
 // the frame before.  SLIDE == 0: all sixteen pairs are loaded at the top of every frame.
 // All builds do the same arithmetic: which one runs does not change a bit of the result.
 template <int LOG2M, bool VEC2, int SLIDE, class R = double>
-__global__ void __launch_bounds__(Fast16Cfg<LOG2M>::T, 2) analysis_fast16_kernel(ParamsT<R> p, AnaArgsT<R> a)
+__global__ void __launch_bounds__(Fast16Cfg<LOG2M>::T, (fast16_waves<R, LOG2M>(2, VOC_F32_16_WAVES))) analysis_fast16_kernel(ParamsT<R> p, AnaArgsT<R> a)
 {
     using C2 = cplx<R>;
     constexpr int M = Fast16Cfg<LOG2M>::M, T = Fast16Cfg<LOG2M>::T;
@@ -491,6 +514,9 @@ __global__ void __launch_bounds__(Fast16Cfg<LOG2M>::T, 2) analysis_fast16_kernel
 #ifndef VOC_SYN16_ROW_PF
 #define VOC_SYN16_ROW_PF 0  // synthesis: bin pairs (of eight) whose STFT row entries are requested a frame ahead
 #endif
+#ifndef VOC_SYN16_ROW_PF_F32
+#define VOC_SYN16_ROW_PF_F32 0  // the same on float (more than none spills there too)
+#endif
 #ifndef VOC_SYN16_ROW_AHEAD
 #define VOC_SYN16_ROW_AHEAD 4  // synthesis: further bin pairs whose row entries are in flight ahead of their use
 #endif
@@ -502,7 +528,7 @@ __global__ void __launch_bounds__(Fast16Cfg<LOG2M>::T, 2) analysis_fast16_kernel
 // thread t owns the sample PAIRS 2 (t + j T), + 1, j = 0..15, of the window, and the partial sums shift by
 // NHP pair slots per frame.
 template <int LOG2M, int NHP, class R = double, bool MAPPED = false>
-__global__ void __launch_bounds__(Fast16Cfg<LOG2M>::T, VOC_SYN16_WAVES) synthesis_fast16_kernel(ParamsT<R> p, SynArgsT<R> a)
+__global__ void __launch_bounds__(Fast16Cfg<LOG2M>::T, (fast16_waves<R, LOG2M>(VOC_SYN16_WAVES, VOC_F32_SYN16_WAVES))) synthesis_fast16_kernel(ParamsT<R> p, SynArgsT<R> a)
 {
     using C2 = cplx<R>;
     constexpr int M = Fast16Cfg<LOG2M>::M, T = Fast16Cfg<LOG2M>::T;
@@ -545,7 +571,7 @@ __global__ void __launch_bounds__(Fast16Cfg<LOG2M>::T, VOC_SYN16_WAVES) synthesi
     // STFT row of a frame: (mag, ph_inc) of the thread's sixteen bins, and of DC / Nyquist in thread 0.  The
     // entries of the first PF bin pairs are requested during the previous frame's transform (a wave has
     // registers for that many), the others at the top of the frame, behind the bin pairs that are already here.
-    constexpr int PF = VOC_SYN16_ROW_PF;
+    constexpr int PF = sizeof(R) == 4 ? VOC_SYN16_ROW_PF_F32 : VOC_SYN16_ROW_PF;
     R mga[8], mgb[8], ica[8], icb[8], mg0 = (R)0, mgm = (R)0, ic0 = (R)0, icm = (R)0;
     auto load_pairs = [&](long long f, int lt, int m0, int m1, bool real_bins) {
         const R *mrow = MAPPED ? mag_row_of(a, c, f) : a.mag + (c * a.F + f) * a.ldk;

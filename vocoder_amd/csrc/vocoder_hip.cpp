@@ -100,6 +100,9 @@ struct voc_ctx {
     // (VOC_FAST16_ANA=0 turns it off), synthesis on request (VOC_FAST16_SYN=1: measured slower, kept for comparison)
     bool fast16_ana = true;
     int fast16_syn = -1;  // -1: only where there is no eight-point kernel (N = 16384)
+    // the same on single-precision contexts (VOC_FAST16_F32_ANA, VOC_FAST16_F32_SYN)
+    bool fast16_ana_f32 = VOC_FAST16_F32_ANA_DEFAULT != 0;
+    int fast16_syn_f32 = VOC_FAST16_F32_SYN_DEFAULT;
 #ifndef VOC_EMU
     bool profiling = false;
     struct Timed { int kind; hipEvent_t start, stop; };
@@ -568,17 +571,20 @@ inline bool fast_sizes(const voc_ctx *c) { return !c->force_generic && !c->blues
 // (stages, signals, streams pushed in any chunking) produces the same bits.
 inline bool fast16_sizes(const voc_ctx *c)
 {
-    return !c->force_generic && !c->bluestein && c->precision == VOC_PRECISION_F64 && c->log2m >= 11 && c->log2m <= 13;
+    return !c->force_generic && !c->bluestein && c->log2m >= 11 && c->log2m <= 13;
 }
 
-inline bool fast16_analysis(const voc_ctx *c) { return c->fast16_ana && fast16_sizes(c); }
+inline bool fast16_ana_on(const voc_ctx *c) { return c->precision == VOC_PRECISION_F32 ? c->fast16_ana_f32 : c->fast16_ana; }
+inline int fast16_syn_on(const voc_ctx *c) { return c->precision == VOC_PRECISION_F32 ? c->fast16_syn_f32 : c->fast16_syn; }
+
+inline bool fast16_analysis(const voc_ctx *c) { return fast16_ana_on(c) && fast16_sizes(c); }
 
 // The sixteen-point synthesis kernel (overlap-add in registers) needs W == N and a hop of 1, 2, 4 or 8 times
 // N/16 samples.  Returns that multiple (the pair slots its overlap-add emits per frame) or 0.
 inline int fast16_hop_slots(const voc_ctx *c, bool synthesis)
 {
     if (!fast16_sizes(c) || c->W != c->N) return 0;
-    if (synthesis ? !(c->fast16_syn == 1 || (c->fast16_syn < 0 && c->log2m == 13)) : !c->fast16_ana) return 0;
+    if (synthesis ? !(fast16_syn_on(c) == 1 || (fast16_syn_on(c) < 0 && c->log2m == 13)) : !fast16_ana_on(c)) return 0;
     const int t2 = c->M / 8;  // 2 T samples
     if (c->H % t2 != 0) return 0;
     const int s = c->H / t2;
@@ -594,29 +600,31 @@ inline bool rows_aligned16(const R *y, long long stride) { return reinterpret_ca
 #define VOC_FOR_EACH_FAST16_LOG2M(X) X(11) X(12) X(13)
 #endif
 
-template <int L>
-void launch_analysis_fast16(voc_ctx *c, const voc::AnaArgsT<double> &a, unsigned grid, bool vec2, int slide, hipStream_t st)
+template <int L, class R>
+void launch_analysis_fast16(voc_ctx *c, const voc::AnaArgsT<R> &a, unsigned grid, bool vec2, int slide, hipStream_t st)
 {
     const dim3 g(grid), b(voc::Fast16Cfg<L>::T);
-    const size_t lds = voc::Fast16Cfg<L>::template lds_bytes<double>();
-    if (!vec2) hipLaunchKernelGGL((voc::analysis_fast16_kernel<L, false, 0, double>), g, b, lds, st, c->params, a);
-    else if (slide == 1) hipLaunchKernelGGL((voc::analysis_fast16_kernel<L, true, 1, double>), g, b, lds, st, c->params, a);
-    else if (slide == 2) hipLaunchKernelGGL((voc::analysis_fast16_kernel<L, true, 2, double>), g, b, lds, st, c->params, a);
-    else if (slide == 4) hipLaunchKernelGGL((voc::analysis_fast16_kernel<L, true, 4, double>), g, b, lds, st, c->params, a);
-    else if (slide == 8) hipLaunchKernelGGL((voc::analysis_fast16_kernel<L, true, 8, double>), g, b, lds, st, c->params, a);
-    else hipLaunchKernelGGL((voc::analysis_fast16_kernel<L, true, 0, double>), g, b, lds, st, c->params, a);
+    const size_t lds = voc::Fast16Cfg<L>::template lds_bytes<R>();
+    const voc::ParamsT<R> &p = params_of<R>(c);
+    if (!vec2) hipLaunchKernelGGL((voc::analysis_fast16_kernel<L, false, 0, R>), g, b, lds, st, p, a);
+    else if (slide == 1) hipLaunchKernelGGL((voc::analysis_fast16_kernel<L, true, 1, R>), g, b, lds, st, p, a);
+    else if (slide == 2) hipLaunchKernelGGL((voc::analysis_fast16_kernel<L, true, 2, R>), g, b, lds, st, p, a);
+    else if (slide == 4) hipLaunchKernelGGL((voc::analysis_fast16_kernel<L, true, 4, R>), g, b, lds, st, p, a);
+    else if (slide == 8) hipLaunchKernelGGL((voc::analysis_fast16_kernel<L, true, 8, R>), g, b, lds, st, p, a);
+    else hipLaunchKernelGGL((voc::analysis_fast16_kernel<L, true, 0, R>), g, b, lds, st, p, a);
 }
 
-template <int L, bool MAPPED>
-void launch_synthesis_fast16(voc_ctx *c, const voc::SynArgsT<double> &a, unsigned grid, int nhp, hipStream_t st)
+template <int L, bool MAPPED, class R>
+void launch_synthesis_fast16(voc_ctx *c, const voc::SynArgsT<R> &a, unsigned grid, int nhp, hipStream_t st)
 {
     const dim3 g(grid), b(voc::Fast16Cfg<L>::T);
-    const size_t lds = voc::Fast16Cfg<L>::template lds_bytes<double>();
+    const size_t lds = voc::Fast16Cfg<L>::template lds_bytes<R>();
+    const voc::ParamsT<R> &p = params_of<R>(c);
     switch (nhp) {
-    case 1: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 1, double, MAPPED>), g, b, lds, st, c->params, a); break;
-    case 2: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 2, double, MAPPED>), g, b, lds, st, c->params, a); break;
-    case 4: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 4, double, MAPPED>), g, b, lds, st, c->params, a); break;
-    default: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 8, double, MAPPED>), g, b, lds, st, c->params, a); break;
+    case 1: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 1, R, MAPPED>), g, b, lds, st, p, a); break;
+    case 2: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 2, R, MAPPED>), g, b, lds, st, p, a); break;
+    case 4: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 4, R, MAPPED>), g, b, lds, st, p, a); break;
+    default: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 8, R, MAPPED>), g, b, lds, st, p, a); break;
     }
 }
 
@@ -652,20 +660,18 @@ bool launch_analysis_fast(voc_ctx *c, const voc::AnaArgsT<R> &a, long long chann
     if (grid > 0x7fffffffLL) throw HipFail{hipErrorInvalidValue, "analysis grid too large"};
     const bool vec2 = c->W == c->N && (reinterpret_cast<uintptr_t>(a.x) % (2 * sizeof(R)) == 0) && a.chan_stride % 2 == 0 &&
                       a.frame_stride % 2 == 0;
-    if constexpr (std::is_same<R, double>::value) {
-        if (fast16_analysis(c)) {
-            // frames cut from one signal, hop 1, 2, 4 or 8 times N/16: the sample window slides in registers
-            const int s16 = (vec2 && a.frame_stride == c->H) ? fast16_hop_slots(c, false) : 0;
-            LaunchTimer timer(c, KIND_ANALYSIS, st);
-            switch (c->log2m) {
-#define X(L) case L: launch_analysis_fast16<L>(c, a, (unsigned)grid, vec2, s16, st); break;
-                VOC_FOR_EACH_FAST16_LOG2M(X)
+    if (fast16_analysis(c)) {
+        // frames cut from one signal, hop 1, 2, 4 or 8 times N/16: the sample window slides in registers
+        const int s16 = (vec2 && a.frame_stride == c->H) ? fast16_hop_slots(c, false) : 0;
+        LaunchTimer timer(c, KIND_ANALYSIS, st);
+        switch (c->log2m) {
+#define X(L) case L: launch_analysis_fast16<L, R>(c, a, (unsigned)grid, vec2, s16, st); break;
+            VOC_FOR_EACH_FAST16_LOG2M(X)
 #undef X
-            }
-            HIPCHK(hipGetLastError());
-            print_stamps("analysis16", 0);
-            return true;
         }
+        HIPCHK(hipGetLastError());
+        print_stamps("analysis16", 0);
+        return true;
     }
     if (!fast_sizes(c)) return false;
     // frames cut from one signal, hop a multiple of 2T: the sample window slides in registers
@@ -730,7 +736,7 @@ inline voc::SynArgsT<double> as_double_args(const voc::SynArgsT<float> &) { retu
 template <class R>
 bool launch_synthesis_fast(voc_ctx *c, const voc::SynArgsT<R> &a, long long channels, bool ola, hipStream_t st)
 {
-    const int s16 = (ola && rows_aligned16(a.out, a.out_stride) && std::is_same<R, double>::value) ? fast16_hop_slots(c, true) : 0;
+    const int s16 = (ola && rows_aligned16(a.out, a.out_stride)) ? fast16_hop_slots(c, true) : 0;
     if (!fast_sizes(c) && s16 == 0) return false;
     const int nh = ola ? fast_ola_nhp(c, a) : 8;
     if (ola && nh == 0 && s16 == 0) return false;
@@ -740,21 +746,19 @@ bool launch_synthesis_fast(voc_ctx *c, const voc::SynArgsT<R> &a, long long chan
     if (grid <= 0) return true;
     if (grid > 0x7fffffffLL) throw HipFail{hipErrorInvalidValue, "synthesis grid too large"};
     LaunchTimer timer(c, KIND_SYNTHESIS, st);
-    if constexpr (std::is_same<R, double>::value) {
-        if (s16 > 0) {
-            switch (c->log2m) {
-#define X(L)                                                                                     \
-    case L:                                                                                      \
-        if (mapped) launch_synthesis_fast16<L, true>(c, a, (unsigned)grid, s16, st);             \
-        else launch_synthesis_fast16<L, false>(c, a, (unsigned)grid, s16, st);                   \
+    if (s16 > 0) {
+        switch (c->log2m) {
+#define X(L)                                                                                                     \
+    case L:                                                                                                      \
+        if (mapped) launch_synthesis_fast16<L, true, double>(c, as_double_args(a), (unsigned)grid, s16, st);      \
+        else launch_synthesis_fast16<L, false, R>(c, a, (unsigned)grid, s16, st);                                \
         break;
-                VOC_FOR_EACH_FAST16_LOG2M(X)
+            VOC_FOR_EACH_FAST16_LOG2M(X)
 #undef X
-            }
-            HIPCHK(hipGetLastError());
-            print_stamps("synthesis16", 1);
-            return true;
         }
+        HIPCHK(hipGetLastError());
+        print_stamps("synthesis16", 1);
+        return true;
     }
     if (!fast_sizes(c)) return false;
     switch (c->log2m) {
@@ -976,7 +980,7 @@ void synthesis_signal_dev(voc_ctx *c, const R *mag, const R *inc, long long ldk,
     if (C <= 0 || F <= 0) return;
     WsUse use(c, st);
     const bool fused = !c->bluestein && (lds_bytes<R>(c, true) <= kLdsLimit ||
-                                         (std::is_same<R, double>::value && fast16_hop_slots(c, true) > 0 && rows_aligned16(y, y_stride)));
+                                         (fast16_hop_slots(c, true) > 0 && rows_aligned16(y, y_stride)));
     const int halo = fused ? (c->W + c->H - 1) / c->H - 1 : 0;
     int tile_len, tiles;
     synthesis_tiling(c, C, F, halo, &tile_len, &tiles);
@@ -1045,8 +1049,10 @@ long long synthesis_slots(const voc_ctx *c)
 {
     if (!fast_sizes(c) && fast16_hop_slots(c, true) == 0) return 0;
     if (c->syn_slots_override > 0) return c->syn_slots_override;  // VOC_SYN_SLOTS: lets small tests reach this path
-    if (fast16_hop_slots(c, true) > 0) {  // sixteen points per thread: M * 16 bytes of LDS and two waves per SIMD
-        const long long t16 = c->M / 16, by_lds16 = c->lds_per_cu / ((long long)c->M * 16), by_regs16 = 8 * 64 / t16;
+    if (fast16_hop_slots(c, true) > 0) {  // sixteen points per thread: one frame of LDS and two (float: three) waves per SIMD
+        const bool f32_16 = c->precision == VOC_PRECISION_F32;
+        const long long t16 = c->M / 16, by_lds16 = c->lds_per_cu / ((long long)c->M * (f32_16 ? 8 : 16)),
+                        by_regs16 = (f32_16 && c->log2m < 13 ? 4 * VOC_F32_SYN16_WAVES : 8) * 64 / t16;
         const long long per_cu16 = by_lds16 < by_regs16 ? by_lds16 : by_regs16;
         return c->cus * (per_cu16 < 1 ? 1 : per_cu16);
     }
@@ -1142,7 +1148,7 @@ void roundtrip_dev(voc_ctx *c, const R *x, long long x_stride, long long len, lo
                                 hipMemcpyDeviceToDevice, st));
     if (F <= 0) return;
 
-    const bool ola16 = std::is_same<R, double>::value && fast16_hop_slots(c, true) > 0 && rows_aligned16(y, y_stride);
+    const bool ola16 = fast16_hop_slots(c, true) > 0 && rows_aligned16(y, y_stride);
     // channels per pass: as many as the workspace holds
     long long group = C;
     std::optional<WsUse> own;  // the library's own workspace is shared between calls; a caller's is the caller's to order
@@ -1322,6 +1328,8 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
         c->force_generic = env_int("VOC_FORCE_GENERIC") != 0;
         c->fast16_ana = !(std::getenv("VOC_FAST16_ANA") && env_int("VOC_FAST16_ANA") == 0);
         c->fast16_syn = std::getenv("VOC_FAST16_SYN") ? (env_int("VOC_FAST16_SYN") != 0 ? 1 : 0) : -1;
+        if (std::getenv("VOC_FAST16_F32_ANA")) c->fast16_ana_f32 = env_int("VOC_FAST16_F32_ANA") != 0;
+        if (std::getenv("VOC_FAST16_F32_SYN")) c->fast16_syn_f32 = env_int("VOC_FAST16_F32_SYN") != 0 ? 1 : 0;
 
         // per-pass Stockham twiddles, laid out as voc::fft_passes reads them: the pass at stride NS
         // (radix r = min(8, M/NS)) occupies entries NS-1 .. NS-1 + (r-1)*NS, [j-1][k] with k fastest,
