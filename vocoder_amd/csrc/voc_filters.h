@@ -60,16 +60,17 @@ VOC_DEV double convolve_at(const double *mag, int K, const double *ker, int len,
     return acc;
 }
 
-VOC_DEV unsigned mulhi32(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
-
-// Philox-4x32-10 (Salmon et al., SC'11): counter (c0..c3), key (k0, k1) -> first two output words
+// Philox-4x32-10 (Salmon et al., SC'11): counter (c0..c3), key (k0, k1) -> first two output words.
+// Each round's two 32 x 32 -> 64 bit products are written as one 64-bit multiplication each (one
+// v_mad_u64_u32 instead of a v_mul_hi_u32 / v_mul_lo_u32 pair: integer multiplications issue at a quarter of
+// the rate of other vector instructions and are all this generator costs).
 VOC_DEV void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned *r0,
                            unsigned *r1)
 {
+#pragma unroll
     for (int round = 0; round < 10; ++round) {
-        const unsigned hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const unsigned hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const unsigned n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
