@@ -17,8 +17,8 @@
  *     {re, im} (16 bytes), the layout of Haskell's `Storable (Complex Double)`.
  *   - N = FFT frame length (vocFrameLength), W = window / input frame length
  *     (vocInputFrameLength, W <= N), H = hop (vocHopSize), K = N/2+1
- *     (vocFreqFrameLength).  This build supports every N in [2, 16384]: powers of
- *     two from 8 on directly, every other length as a chirp-z transform (double precision
+ *     (vocFreqFrameLength).  This build supports every N in [2, 32768]: powers of
+ *     two from 8 to 16384 directly, every other length as a chirp-z transform (double precision
  *     only; above 4096 through device memory, an order of magnitude slower).
  *   - the caller owns every buffer; the library owns only the opaque voc_ctx.
  *   - entry points without a `_dev` suffix take HOST pointers and copy through

@@ -48,3 +48,25 @@ def test_filters_and_stream_on_a_non_power_of_two_length(emu_lib, orc):
     st = S.Stream(par, 1)
     y = np.concatenate([st.push(x[:, :77]), st.push(x[:, 77:]), st.flush()], axis=1)
     assert np.array_equal(y, y_ref)
+
+
+def test_length_above_16384(emu_lib, orc):
+    """Frame lengths above 16384, powers of two included, take the chirp-z transform through device memory with
+    eight interleaved 8192-point transforms; their STFT rows (up to 16385 bins) go through the filter kernel's
+    build for long rows, which stages one array at a time in LDS."""
+    from vocoder_amd import vocoder as V, filter as Fl
+    rng = np.random.default_rng(6)
+    Hh.check_fft_layer(emu_lib, orc, 32768, 32768, 8192, rng)
+    Hh.check_stages(emu_lib, orc, 16500, 16000, 4000, 2, 1, rng)
+    n = 32768
+    par = V.VocoderParams(n, 8192, orc.make_window("hann", n), lib=emu_lib)
+    mag, inc = rng.uniform(0, 1, (1, 2, par.K)), rng.uniform(-1, 1, (1, 2, par.K))
+    chain = Fl.pitch_shift_interpolate(1.5) >> Fl.lowpass_butterworth(2.0, 5000.0) >> Fl.envelope_filter(5)
+    spec = [("pitch_shift", 1.5), ("lowpass_butterworth", 2.0, 5000.0), ("envelope", 5)]
+    m, i = chain.bind(par, 48000.0 / n).apply(mag, inc)
+    mo, io = orc.apply_filter(48000.0 / n, spec, mag, inc)
+    assert np.allclose(m, mo, rtol=1e-12, atol=1e-15) and np.array_equal(i, io)
+    par.close()
+    with pytest.raises(V.VocoderError) as e:
+        V.VocoderParams(32770, 8192, np.ones(1000), lib=emu_lib)
+    assert e.value.status == -2

@@ -292,6 +292,38 @@ def test_lengths_above_4096_that_are_not_powers_of_two(gpu_lib, orc, n, w, h, f,
         par.close()
 
 
+@pytest.mark.parametrize("n,w,h,f,c", [(32768, 32768, 8192, 3, 2), (20000, 18000, 5000, 2, 1), (32767, 32767, 8191, 1, 1)])
+def test_lengths_above_16384(gpu_lib, orc, n, w, h, f, c):
+    """Frame lengths above 16384 (powers of two included) run as chirp-z transforms of eight interleaved 8192-point
+    transforms through device memory: FFT layer, stages, fused round trip, a filter chain on rows of up to 16385
+    bins (one staging array at a time in LDS) and a stream, against the oracle."""
+    from vocoder_amd import vocoder as V, conduit as Cd, stream as S, filter as Fl
+    rng = np.random.default_rng(n)
+    Hh.check_fft_layer(gpu_lib, orc, n, w, h, rng)
+    Hh.check_stages(gpu_lib, orc, n, w, h, f, c, rng)
+    Hh.check_roundtrip(gpu_lib, orc, n, w, h, w + h * f + 3, c, rng)
+    if n in (32768, 20000):
+        win = orc.make_window("hann", w)
+        par = V.VocoderParams(n, h, win, lib=gpu_lib)
+        mag, inc = rng.uniform(0, 1, (2, 3, par.K)), rng.uniform(-1, 1, (2, 3, par.K))
+        chain = Fl.pitch_shift_interpolate(1.5) >> Fl.lowpass_butterworth(2.0, 5000.0) >> Fl.envelope_filter(32)
+        m, i = chain.bind(par, 48000.0 / n).apply(mag, inc)
+        mo, io = orc.apply_filter(48000.0 / n, [("pitch_shift", 1.5), ("lowpass_butterworth", 2.0, 5000.0), ("envelope", 32)], mag, inc)
+        assert np.allclose(m, mo, rtol=1e-10, atol=1e-15) and np.array_equal(i, io)
+        filt = (Fl.pitch_shift_interpolate(0.75) >> Fl.random_phase_filter(5) >> Fl.play_speed(2)).bind(par, 48000.0 / n)
+        x = rng.standard_normal((2, w + h * 6 + 2))
+        y_ref = Cd.process_with(par, x)[0]
+        st = S.Stream(par, 2)
+        y = np.concatenate([st.push(x[:, :7777]), st.push(x[:, 7777:]), st.flush()], axis=1)
+        assert np.array_equal(y, y_ref)
+        import torch
+        yf = Cd.process_filter_dev(par, filt, torch.from_numpy(x).cuda())[0]
+        sf = S.Stream(par, 2, filt=filt)
+        y2 = np.concatenate([sf.push(x[:, :50000]), sf.push(x[:, 50000:]), sf.flush()], axis=1)
+        assert np.array_equal(y2, yf.cpu().numpy())
+        par.close()
+
+
 def test_interleaved_layout_on_device(gpu_lib, orc):
     """vocoder-audio cuts frames of W*C interleaved samples at hops of H*C and splits each frame per
     channel (Audio.hs:51-55): de-interleaving once and framing each planar channel at (W, H) gives the

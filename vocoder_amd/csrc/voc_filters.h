@@ -95,6 +95,9 @@ VOC_DEV double convolve_fast_at(const double *mag, int K, const double *ker, int
     return acc;
 }
 
+// rows too long for two staging arrays in LDS
+constexpr bool filter_one_array(int log2m) { return log2m >= 14; }
+
 template <int LOG2M>
 struct FiltCfg {
     static constexpr int M = 1 << LOG2M;
@@ -104,7 +107,8 @@ struct FiltCfg {
 
 // One workgroup per STFT row at a time.  The row lives in registers (thread t holds bins t + T*j);
 // operations that read neighbouring bins stage it through LDS (2 * (K+1) doubles, only allocated
-// when the chain holds such an operation).
+// when the chain holds such an operation; rows of more than 8193 bins -- LOG2M = 14, frame lengths above
+// 16384 -- have room for one array only and stage the moduli and the increments one after the other).
 // S: the type the STFT is stored in.  The arithmetic is the reference's, in double, whatever S is: a float
 // STFT (single-precision contexts) is widened on load and rounded once on store.
 template <int LOG2M, class S = double>
@@ -118,7 +122,8 @@ __global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p
     constexpr int T = Cf::T, NE = Cf::NE;
     const int K = p.K;  // at most M + 1 (M + 1 for power-of-two frame lengths)
     VOC_SMEM(double, lds);
-    double *lm = lds, *li = lds + ((K + 1) & ~1);
+    constexpr bool ONE = filter_one_array(LOG2M);
+    double *lm = lds, *li = ONE ? lds : lds + ((K + 1) & ~1);
     const int tid = threadIdx.x;
     const double ee = 5.9604644775390625e-08;  // 2**(-24), Filter.hs:147
     for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
@@ -150,7 +155,10 @@ __global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
                     const int k = tid + T * j;
-                    if (k < K) { lm[k] = m[j]; li[k] = ic[j]; }
+                    if (k < K) {
+                        lm[k] = m[j];
+                        if (!ONE) li[k] = ic[j];
+                    }
                 }
                 __syncthreads();
 #pragma unroll
@@ -158,10 +166,24 @@ __global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p
                     const int k = tid + T * j;
                     if (k < K) {
                         m[j] = interpolate_at(lm, K, op.a, k);
-                        ic[j] = interpolate_at(li, K, op.a, k) / op.a;
+                        if (!ONE) ic[j] = interpolate_at(li, K, op.a, k) / op.a;
                     }
                 }
                 __syncthreads();
+                if (ONE) {
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) {
+                        const int k = tid + T * j;
+                        if (k < K) li[k] = ic[j];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) {
+                        const int k = tid + T * j;
+                        if (k < K) ic[j] = interpolate_at(li, K, op.a, k) / op.a;
+                    }
+                    __syncthreads();
+                }
                 break;
             case FOP_CONV:  // convolutionFilter (Filter.hs:140-141): amplitudeFilter0 zeroes ph_inc
 #pragma unroll

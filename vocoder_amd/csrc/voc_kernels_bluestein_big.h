@@ -1,9 +1,10 @@
-// voc_kernels_bluestein_big.h -- frame lengths above 4096 that are not powers of two (N <= 16384).
+// voc_kernels_bluestein_big.h -- frame lengths above 4096 that are not powers of two, and every frame
+// length above 16384 (N <= 32768).
 //
 // The reference's FFT (vector-fftw, vocoder/src/Vocoder.hs:49-50,115) accepts any length.  The chirp-z
 // transform of voc_kernels_bluestein.h needs a power-of-two transform of L >= 2N - 1 points, which for
-// these lengths (L = 16384 or 32768 complex points) no longer fits in LDS.  Here it runs through
-// device memory, L = L1 * P with P = 8192 (the largest LDS-resident transform) and L1 = 2 or 4:
+// these lengths (L = 16384 to 65536 complex points) no longer fits in LDS.  Here it runs through
+// device memory, L = L1 * P with P = 8192 (the largest LDS-resident transform) and L1 = 2, 4 or 8:
 //     A[k2 + P k1] = sum_n1 W_L1^(n1 k1) [ W_L^(n1 k2) sum_n2 a[n1 + L1 n2] W_P^(n2 k2) ]
 // i.e. L1 interleaved P-point transforms (one workgroup each, first kernel), a twiddle, and an
 // L1-point transform across them (a few registers per thread, second kernel).  The second kernel also
@@ -85,15 +86,20 @@ __global__ void __launch_bounds__(Cfg<kBigLog2P>::T) blue_big_first_kernel(Param
     }
 }
 
-// L1-point DFT in registers, natural order in and out (L1 = 2 or 4)
-VOC_DEV void small_dft(double2 (&v)[4], int L1)
+// L1-point DFT in registers, natural order in and out (L1 = 2, 4 or 8; entries from L1 on are zero and stay unused)
+VOC_DEV void small_dft(double2 (&v)[8], int L1)
 {
     if (L1 == 2) {
         const double2 t = v[0];
         v[0] = cadd(t, v[1]);
         v[1] = csub(t, v[1]);
+    } else if (L1 == 4) {
+        double2 q[4] = {v[0], v[1], v[2], v[3]};
+        dft<4>(q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = q[j];
     } else {
-        dft<4>(v);
+        dft<8>(v);
     }
 }
 
@@ -108,16 +114,16 @@ __global__ void blue_big_middle_kernel(BlueBigTab b, double2 *u, long long frame
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
         const int k2 = (int)(g % P);
         double2 *row = u + (g / P) * L + (long long)L1 * k2;
-        double2 v[4];
+        double2 v[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = j < L1 ? row[j] : make_double2(0.0, 0.0);
+        for (int j = 0; j < 8; ++j) v[j] = j < L1 ? row[j] : make_double2(0.0, 0.0);
         small_dft(v, L1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 8; ++j)
             if (j < L1) v[j] = cconj(cmul(v[j], b.bfft[k2 + P * j]));
         small_dft(v, L1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 8; ++j)
             if (j < L1) row[j] = cmul(v[j], b.wl[(int)(((long long)k2 * j) % L)]);
     }
 }

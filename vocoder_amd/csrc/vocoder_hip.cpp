@@ -1261,7 +1261,7 @@ VOC_EXPORT const char *voc_strerror(int32_t s)
     switch (s) {
     case VOC_OK: return "ok";
     case VOC_ERR_INVALID: return "invalid argument";
-    case VOC_ERR_UNSUPPORTED: return "unsupported frame length or precision (frame length: 2 to 16384; single precision: powers of two from 8)";
+    case VOC_ERR_UNSUPPORTED: return "unsupported frame length or precision (frame length: 2 to 32768; single precision: powers of two from 8 to 16384)";
     case VOC_ERR_HIP: return "HIP runtime call failed";
     case VOC_ERR_NOMEM: return "out of memory";
     case VOC_ERR_SIZE: return "size mismatch";
@@ -1273,6 +1273,8 @@ VOC_EXPORT const char *voc_strerror(int32_t s)
 
 VOC_EXPORT const char *voc_last_hip_error(const voc_ctx *ctx) { return ctx ? ctx->hip_err.c_str() : ""; }
 
+constexpr int kMaxFrameLength = 32768;  // chirp-z transform of 8 * 8192 points (voc_kernels_bluestein_big.h)
+
 VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, int32_t W, int32_t device,
                                   int32_t precision, voc_ctx **out)
 {
@@ -1282,7 +1284,8 @@ VOC_EXPORT int32_t voc_ctx_create(int32_t N, int32_t H, const double *window, in
     if (W > N) return VOC_ERR_INVALID;  // addZeroPadding: input longer than target length (Vocoder.hs:132)
     if (precision != VOC_PRECISION_F64 && precision != VOC_PRECISION_F32) return VOC_ERR_UNSUPPORTED;
     const bool pow2 = N >= 8 && N <= 16384 && (N & (N - 1)) == 0;
-    const bool chirp = !pow2 && N >= 2 && N <= 16384 && precision == VOC_PRECISION_F64;
+    // every other length, and the powers of two above 16384, go through the chirp-z transform
+    const bool chirp = !pow2 && N >= 2 && N <= kMaxFrameLength && precision == VOC_PRECISION_F64;
     const bool chirp_big = chirp && N > 4096;  // its transform no longer fits in LDS
     if (!pow2 && !chirp) return VOC_ERR_UNSUPPORTED;
     voc_ctx *c = new (std::nothrow) voc_ctx;
