@@ -38,13 +38,14 @@ def test_status_strings_and_argument_checks_without_a_gpu():
     from vocoder_amd._ffi import Library
     lib = Library()
     assert lib.dll.voc_strerror(0) == b"ok"
-    assert b"2 to 16384" in lib.dll.voc_strerror(-2)
+    assert b"2 to 32768" in lib.dll.voc_strerror(-2)
     h = ctypes.c_void_p()
     w = (ctypes.c_double * 16)(*([1.0] * 16))
     # argument errors are reported before any device is touched
     assert lib.dll.voc_ctx_create(8, 2, w, 16, 0, 0, ctypes.byref(h)) == -1      # W > N (Vocoder.hs:132)
-    assert lib.dll.voc_ctx_create(20000, 2, w, 16, 0, 0, ctypes.byref(h)) == -2  # above 16384
-    assert lib.dll.voc_ctx_create(32768, 2, w, 16, 0, 0, ctypes.byref(h)) == -2  # power of two above 16384
+    assert lib.dll.voc_ctx_create(40000, 2, w, 16, 0, 0, ctypes.byref(h)) == -2  # above 32768
+    assert lib.dll.voc_ctx_create(65536, 2, w, 16, 0, 0, ctypes.byref(h)) == -2  # power of two above 32768
+    assert lib.dll.voc_ctx_create(32768, 2, w, 16, 0, 1, ctypes.byref(h)) == -2  # single precision: up to 16384
     assert lib.dll.voc_ctx_create(12, 2, w, 12, 0, 1, ctypes.byref(h)) == -2     # single precision: powers of two only
     assert lib.dll.voc_ctx_create(16, 0, w, 16, 0, 0, ctypes.byref(h)) == -1     # hop < 1
     assert lib.dll.voc_ctx_create(16, 4, w, 16, 0, 7, ctypes.byref(h)) == -2     # unknown precision
