@@ -547,12 +547,57 @@ VOC_DEV constexpr int nat_idx(int n)
 // LDS area (other threads may still be reading the last pass' input).
 // twl: optional table in LDS, the twiddle rows of the passes at stride 8 (56 entries) and 64 (448 entries).
 // `early` is called once before the last pass reads its input: the place for loads that the caller uses right after the transform.
+// ldsB (with KEEP_LAST and a fourth pass only): a second buffer of M elements.  The exchanges then alternate
+// between the two -- first-pass results to ldsB, second-pass results to lds, third-pass results to ldsB -- and
+// each needs ONE barrier, between its writes and its reads: the buffer an exchange writes was last read one
+// exchange earlier, and every thread has passed the barrier in between.  The caller's own writes to lds
+// before the next transform need no barrier after this call either (lds was last read before the third barrier).
 struct NoHook { VOC_DEV void operator()() const {} };
-template <int LOG2M, bool KEEP_LAST = false, class C2, class Prefetch, class Early = NoHook>
+template <int LOG2M, bool KEEP_LAST = false, bool TWO_BUFFERS = false, class C2, class Prefetch, class Early = NoHook>
 VOC_DEV void fft_after_first(C2 *lds, const FastTw<LOG2M, C2> &t, int tid, C2 (&v)[8], Prefetch prefetch,
-                             const C2 *twl = nullptr, Early early = Early())
+                             const C2 *twl = nullptr, Early early = Early(), C2 *ldsB = nullptr)
 {
     constexpr int R4 = FastCfg<LOG2M>::R4;
+    static_assert(!TWO_BUFFERS || (KEEP_LAST && R4 > 1), "two buffers: four passes, last results in registers");
+    if constexpr (TWO_BUFFERS) {
+        {
+            // (a scheduling fence where the other form has a barrier: without it the compiler overlaps the passes
+            //  and runs out of registers)
+            sched_fence();
+            store8<LOG2M, 1>(ldsB, tid, v);
+            __syncthreads();
+            load8<LOG2M>(ldsB, tid, v);
+            if (twl) {
+                twiddle8_tab(v, twl + (tid & 7), 8);
+                dft<8>(v);
+            } else if (VOC_FMA_BF) {
+                dft8_tw(v, t.b);
+            } else {
+                twiddle8(v, t.b);
+                dft<8>(v);
+            }
+            sched_fence();
+            store8<LOG2M, 8>(lds, tid, v);
+            __syncthreads();
+            load8<LOG2M>(lds, tid, v);
+            if (twl) {
+                twiddle8_tab(v, twl + 56 + (tid & 63), 64);
+                dft<8>(v);
+            } else if (VOC_FMA_BF) {
+                dft8_tw(v, t.c);
+            } else {
+                twiddle8(v, t.c);
+                dft<8>(v);
+            }
+            sched_fence();
+            store8<LOG2M, 64>(ldsB, tid, v);
+            __syncthreads();
+            early();
+            pass4_compute<LOG2M>(ldsB, tid, t, v);
+            prefetch();
+            return;
+        }
+    }
     __syncthreads();
     store8<LOG2M, 1>(lds, tid, v);
     __syncthreads();
@@ -851,6 +896,28 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
 template <int LOG2M, bool OLA, class R>
 constexpr bool syn_fat() { return VOC_SYN_FAT != 0 && LOG2M >= 10 && OLA && sizeof(R) == 8; }
 
+// Whether that kernel's transform alternates between two LDS buffers (fft_after_first, ldsB): one barrier per
+// exchange instead of two and none at the end of the frame, for M more elements of LDS per workgroup -- which
+// the two-wave build has room for from N = 4096 up (N = 4096: 2 x (2 x 32 KB + 8 KB) per CU).  Measured
+// (MI355X, metric shape, same box): four barriers per frame instead of eight leave the kernel where it was,
+// 27.3 against 27.1 ms -- it does not wait at barriers -- so this is off.
+#ifndef VOC_SYN_PINGPONG
+#define VOC_SYN_PINGPONG 0
+#endif
+template <int LOG2M, bool OLA, class R>
+constexpr bool syn_pingpong()
+{
+    return VOC_SYN_PINGPONG != 0 && syn_fat<LOG2M, OLA, R>() && LOG2M >= 11 && VOC_LAST_IN_REGS != 0 && VOC_SYN_PHASE_REGS != 0 &&
+           VOC_SYN_SINCOS_TAB == 0 && FastCfg<LOG2M>::R4 > 1;
+}
+// LDS of the synthesis kernel: the transform's buffer and the K phases (or, with the phases in registers, tables
+// in their place); with two transform buffers, 512 elements of tables between them.
+template <int LOG2M, bool OLA, class R>
+constexpr int syn_lds_bytes()
+{
+    return syn_pingpong<LOG2M, OLA, R>() ? (2 * FastCfg<LOG2M>::M + 512) * 2 * (int)sizeof(R) : FastCfg<LOG2M>::template lds_bytes<R>();
+}
+
 // OLA = false: frames out ([C][F][W]).
 // OLA = true: overlap-add in registers.  Requires W == N and H = NHP * 2T: thread t owns the sample
 // PAIRS (2(t + jT), 2(t + jT) + 1), j = 0..7, of the N-sample window -- one complex LDS element,
@@ -884,6 +951,8 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, (syn_fat<LOG2M, OLA, R>() ?
     // needs 133 instead of 166 registers and runs 5-11 % faster at N >= 2048; the one-wave workgroups
     // of N = 1024 are 4 % faster with it.
     constexpr bool SFAT = syn_fat<LOG2M, OLA, R>();
+    constexpr bool PP = syn_pingpong<LOG2M, OLA, R>();
+    C2 *ldsB = PP ? lds + FastCfg<LOG2M>::LDS_CPLX + 512 : nullptr;
     constexpr bool ROW_PF = SFAT || VOC_SYN_ROW_PREFETCH == 1 || (VOC_SYN_ROW_PREFETCH == 2 && LOG2M <= 9);
     constexpr bool LEAN = !ROW_PF || SFAT;  // the branch-free sine / cosine pays only with the registers the prefetch took
     // ... and so does keeping the accumulated phases of this thread's eight bins (and of DC / Nyquist
@@ -1070,11 +1139,11 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, (syn_fat<LOG2M, OLA, R>() ?
 #pragma unroll
             for (int j = j0; j < j1; ++j) wv[j] = at_bytes(reinterpret_cast<const C2 *>(VOC_SYN_WIN_SCALED ? p.window_n : p.window) + j * T, lane16, 0);
         };
-        fft_after_first<LOG2M, KEEP_OUT>(lds, tw, lt, v, [&]() {
+        fft_after_first<LOG2M, KEEP_OUT, PP>(lds, tw, lt, v, [&]() {
             if (ROW_PF && !SFAT && f + 1 < f1) load_row(f + 1, lt);
         }, TW_LDS ? twl : nullptr, [&]() {
             if constexpr (!SFAT) load_win(NP - WIN_EARLY, NP);
-        });
+        }, ldsB);
         if constexpr (SFAT) {
 #pragma unroll
             for (int j = 0; j < NP; ++j) wv[j] = wres[j];
@@ -1131,7 +1200,8 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, (syn_fat<LOG2M, OLA, R>() ?
             }
         }
         VOC_STAMP(4);
-        __syncthreads();  // FFT buffer is rewritten by the next frame's spectrum
+        if constexpr (PP) sched_fence();
+        else __syncthreads();  // FFT buffer is rewritten by the next frame's spectrum
         VOC_STAMP(5);
     }
     VOC_STAMP_FLUSH(1);

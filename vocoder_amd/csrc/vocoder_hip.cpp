@@ -719,7 +719,7 @@ template <int L, bool OLA, class R, bool MAPPED = false>
 void launch_synthesis_fast_nh(voc_ctx *c, const voc::SynArgsT<R> &a, unsigned grid, int nhp, hipStream_t st)
 {
     const dim3 g(grid), b(voc::FastCfg<L>::T);
-    const size_t lds = voc::FastCfg<L>::template lds_bytes<R>();
+    const size_t lds = voc::syn_lds_bytes<L, OLA, R>();
     switch (nhp) {
     case 1: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 1, R, MAPPED>), g, b, lds, st, params_of<R>(c), a); break;
     case 2: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 2, R, MAPPED>), g, b, lds, st, params_of<R>(c), a); break;
@@ -1058,8 +1058,9 @@ long long synthesis_slots(const voc_ctx *c)
     }
     const bool f32 = c->precision == VOC_PRECISION_F32;
     const long long t = c->M / 8;
-    const long long lds = (long long)(c->M * 2 + ((c->K + 1) & ~1)) * (f32 ? 4 : 8);  // FastCfg::lds_bytes
     const bool fat = VOC_SYN_FAT != 0 && c->log2m >= 10 && !f32;  // voc::syn_fat: two waves per SIMD instead of three
+    const bool pingpong = fat && c->log2m >= 11 && voc::syn_pingpong<11, true, double>();  // voc::syn_lds_bytes
+    const long long lds = pingpong ? (long long)(2 * c->M + 512) * 16 : (long long)(c->M * 2 + ((c->K + 1) & ~1)) * (f32 ? 4 : 8);
     long long by_lds = c->lds_per_cu / lds, by_regs = (f32 ? 16 : (fat ? 8 : 12)) * 64 / t;
     long long per_cu = by_lds < by_regs ? by_lds : by_regs;
     if (per_cu < 1) per_cu = 1;
