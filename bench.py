@@ -157,9 +157,10 @@ def make_filter(name, par):
     return chain.bind(par, float(RATE) / par.N)
 
 
-def parity_check(par, win, x, y, streams=3):
+def parity_check(par, win, x, y, streams=3, bar=1e-9):
     """Streams 0..streams-1 of a metric step that started from zero phases against the oracle: relative L2 of the
-    output samples (bar 1e-9), and the leftover-free length check."""
+    output samples (bar 1e-9; the single-precision variant is held to its own, looser bar against the same
+    double-precision oracle), and the leftover-free length check."""
     import oracle
     oracle.build()
     worst, frames = 0.0, 0
@@ -170,7 +171,7 @@ def parity_check(par, win, x, y, streams=3):
             return {"ok": False, "error": f"stream {s_}: {got.shape} samples, oracle {r['y'].shape}"}
         worst = max(worst, float(np.linalg.norm(got - r["y"]) / np.linalg.norm(r["y"])))
         frames += int(r["nframes"])
-    return {"ok": bool(worst <= 1e-9), "rel_l2_max": worst, "bar": 1e-9, "streams": streams, "frames": frames,
+    return {"ok": bool(worst <= bar), "rel_l2_max": worst, "bar": bar, "streams": streams, "frames": frames,
             "against": "CPU oracle (C restatement of the reference path) on the same samples, zero initial phases"}
 
 
@@ -423,7 +424,9 @@ def main():
             aph.zero_(); sph.zero_()
             step()
             torch.cuda.synchronize()
-            out["parity"] = parity_check(par, win, x, y)
+            # (single precision: 60 s of the metric signal stay within 1e-3 of the double-precision oracle, the
+            #  float increments' rounding random-walking in the noise part; measured 2.8e-4)
+            out["parity"] = parity_check(par, win, x, y, bar=1e-3 if f32 else 1e-9)
         if world == 1 and not args.no_cpu_baseline and filt is None:
             ncpu = min(args.cpu_streams, c)
             v, nfr, secs = cpu_baseline(win, x[:ncpu].double().cpu().numpy())

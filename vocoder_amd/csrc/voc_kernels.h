@@ -670,6 +670,150 @@ VOC_DEV float phase_inc(const ParamsT<float> &p, int k, float ph_diff)
     return (float)(p.hop_pow2 ? s * (double)p.inv_hop : s / (double)p.hop_d);
 }
 
+// ---- single precision, two bins at a time.
+// A plain fp32 instruction issues at the rate of an fp64 one on this chip; only the packed forms (v_pk_fma_f32,
+// v_pk_mul_f32, v_pk_add_f32) do two lanes' worth per issue slot.  The specialised kernels work on bin pairs
+// (k, M - k) whose two bins go through the same arithmetic, so that arithmetic is written here on two-lane
+// vectors: products and sums pack; comparisons, selects, conversions, floor / rint and the reciprocal and
+// square-root seeds stay one per bin, and the case distinctions are turned into 0 / 1 or +-1 factors so that
+// only the factor is selected.  Same approximations as the one-bin float versions, to within float rounding.
+#ifndef VOC_F32_PACKED
+#define VOC_F32_PACKED 1
+#endif
+#ifdef VOC_EMU
+struct f32x2 { float x, y; };
+VOC_DEV f32x2 operator+(f32x2 a, f32x2 b) { return f32x2{a.x + b.x, a.y + b.y}; }
+VOC_DEV f32x2 operator-(f32x2 a, f32x2 b) { return f32x2{a.x - b.x, a.y - b.y}; }
+VOC_DEV f32x2 operator*(f32x2 a, f32x2 b) { return f32x2{a.x * b.x, a.y * b.y}; }
+VOC_DEV f32x2 operator-(f32x2 a) { return f32x2{-a.x, -a.y}; }
+VOC_DEV f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return f32x2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+#else
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+VOC_DEV f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
+VOC_DEV f32x2 pk2(float a, float b)
+{
+    f32x2 r;
+    r.x = a;
+    r.y = b;
+    return r;
+}
+VOC_DEV f32x2 splat2(float c) { return pk2(c, c); }
+// a kernel argument used as one lane-uniform float (kept in its scalar register: without this the compiler
+// gathers neighbouring arguments into vectors through the stack)
+VOC_DEV float uniform_f(float v)
+{
+#ifndef VOC_EMU
+    asm("" : "+s"(v));
+#endif
+    return v;
+}
+VOC_DEV unsigned f32_bits(float v) { return __builtin_bit_cast(unsigned, v); }
+VOC_DEV float f32_of(unsigned b) { return __builtin_bit_cast(float, b); }
+
+// frameFromComplex of the bins xa + i ya and xb + i yb.  The pair (max, min) of (|x|, |y|) is scaled by the power
+// of two that brings the larger into [1, 2) -- a product with a float assembled from the exponent bits, and the
+// magnitude is scaled back by the float with just those bits -- so squares neither overflow nor underflow;
+// atan(min / max) with the fold at tan(pi/8) before the division; the octant is undone by two +-1 factors.
+// A zero bin gives magnitude 0 and phase 0 (pi for x = -0); denormal components count as zero.
+VOC_DEV void hs_polar_pair(float xa, float ya, float xb, float yb, float &ma, float &pa, float &mb, float &pb)
+{
+    const f32x2 mx = pk2(fmaxf(fabsf(xa), fabsf(ya)), fmaxf(fabsf(xb), fabsf(yb)));
+    const f32x2 mn = pk2(fminf(fabsf(xa), fabsf(ya)), fminf(fabsf(xb), fabsf(yb)));
+    const unsigned ea = f32_bits(mx.x) & 0x7f800000u, eb = f32_bits(mx.y) & 0x7f800000u;
+    const f32x2 down = pk2(f32_of(0x7f000000u - ea), f32_of(0x7f000000u - eb));  // 2^-e (2^127 for a zero bin: 0 stays 0)
+    const f32x2 up = pk2(f32_of(ea), f32_of(eb));                                  // 2^e
+    const f32x2 MX = mx * down, MN = mn * down;                                    // MX in [1, 2) or 0
+    const f32x2 ss = fma2(MN, MN, MX * MX);
+#ifdef VOC_EMU
+    const f32x2 r = pk2(sqrtf(ss.x), sqrtf(ss.y));
+#else
+    const f32x2 r = pk2(__builtin_amdgcn_sqrtf(ss.x), __builtin_amdgcn_sqrtf(ss.y));
+#endif
+    const f32x2 mag = r * up;
+    const f32x2 lim = MX * splat2(0.41421356f);
+    const f32x2 f = pk2(MN.x > lim.x ? 1.0f : 0.0f, MN.y > lim.y ? 1.0f : 0.0f);
+    const f32x2 num = fma2(-f, MX, MN);
+    const f32x2 d0 = fma2(f, MN, MX);
+    const f32x2 den = pk2(fmaxf(d0.x, 1e-30f), fmaxf(d0.y, 1e-30f));
+    const f32x2 rc = pk2(approx_rcp(den.x), approx_rcp(den.y));
+    f32x2 q = num * rc;
+    q = fma2(fma2(-den, q, num), rc, q);
+    const f32x2 z = q * q;
+    f32x2 p = splat2(-0.06466829776763916f);
+    p = fma2(p, z, splat2(0.10748856514692307f));
+    p = fma2(p, z, splat2(-0.14264507591724396f));
+    p = fma2(p, z, splat2(0.19999559223651886f));
+    p = fma2(p, z, splat2(-0.3333333134651184f));
+    f32x2 t = fma2(q * z, p, q);
+    t = fma2(f, splat2(0.78539816f), t);
+    // |y| > |x|: pi/2 - t;  x < 0 (or -0): pi - t;  then the sign of y
+    const f32x2 s1 = pk2(fabsf(ya) > fabsf(xa) ? -1.0f : 1.0f, fabsf(yb) > fabsf(xb) ? -1.0f : 1.0f);
+    t = fma2(s1, t, fma2(-s1, splat2(0.78539816f), splat2(0.78539816f)));
+    const f32x2 s2 = pk2(copysignf(1.0f, xa), copysignf(1.0f, xb));
+    t = fma2(s2, t, fma2(-s2, splat2(1.57079633f), splat2(1.57079633f)));
+    ma = mag.x;
+    mb = mag.y;
+    pa = copysignf(t.x, ya);
+    pb = copysignf(t.y, yb);
+}
+
+// phase_inc_pow2 of the bins ka and kb
+VOC_DEV void phase_inc_pow2_pair(const ParamsT<float> &p, int ka, int kb, float da, float db, float &ia, float &ib)
+{
+    const f32x2 kf = pk2((float)ka, (float)kb), km = pk2((float)(ka & p.turn_mask), (float)(kb & p.turn_mask));
+    const f32x2 hi = splat2(uniform_f(p.om1_hi));
+    const f32x2 x = fma2(-km, hi, pk2(da, db));                                    // ph_diff - (k mod N/H) omega1
+    const f32x2 u = (x + splat2(kPiF)) * splat2(kInvTwoPiF);
+    const f32x2 n = pk2(floorf(u.x), floorf(u.y));
+    const f32x2 w = fma2(-n, splat2(kTwoPiLoF), fma2(-n, splat2(kTwoPiHiF), x));   // wrap_floor_f
+    const f32x2 om_hi = kf * hi;
+    const f32x2 om_lo = fma2(kf, splat2(uniform_f(p.om1_lo)), fma2(kf, hi, -om_hi));
+    const f32x2 r = (om_hi + (w + om_lo)) * splat2(uniform_f(p.inv_hop));
+    ia = r.x;
+    ib = r.y;
+}
+
+// synthesisStep of two bins: phase steps (phase_step for float), then mkPolar; LEAN is accepted and ignored
+VOC_DEV void synthesize_pair(const ParamsT<float> &p, float mga, float ica, float &pha, float mgb, float icb, float &phb,
+                             float2 &A, float2 &B)
+{
+    const f32x2 t = pk2(ica, icb) * splat2(uniform_f((float)p.hop_d));
+    const f32x2 n1 = pk2(rintf(t.x * kInvTwoPiF), rintf(t.y * kInvTwoPiF));
+    const f32x2 tn = fma2(-n1, splat2(kTwoPiLoF), fma2(-n1, splat2(kTwoPiHiF), t));   // wrap_near_f
+    const f32x2 s = pk2(pha, phb) + tn;
+    const f32x2 u = (s + splat2(kPiF)) * splat2(kInvTwoPiF);
+    const f32x2 n2 = pk2(floorf(u.x), floorf(u.y));
+    const f32x2 ph = fma2(-n2, splat2(kTwoPiLoF), fma2(-n2, splat2(kTwoPiHiF), s));   // wrap_floor_f
+    pha = ph.x;
+    phb = ph.y;
+    // fast_sincos for float, both bins
+    const f32x2 v = ph * splat2(0.636619772f);
+    const f32x2 n = pk2(rintf(v.x), rintf(v.y));
+    const int qa = (int)n.x, qb = (int)n.y;
+    f32x2 r = fma2(-n, splat2(1.57079637f), ph);
+    r = fma2(-n, splat2(-4.37113883e-8f), r);
+    const f32x2 z = r * r;
+    f32x2 ps = splat2(-0.00019588008581195027f);
+    ps = fma2(ps, z, splat2(0.008332748897373676f));
+    ps = fma2(ps, z, splat2(-0.166666641831398f));
+    const f32x2 sn = fma2(r * z, ps, r);
+    f32x2 pc = splat2(2.454804052831605e-05f);
+    pc = fma2(pc, z, splat2(-0.001388830365613103f));
+    pc = fma2(pc, z, splat2(0.0416666641831398f));
+    const f32x2 cs = fma2(z * z, pc, fma2(splat2(-0.5f), z, splat2(1.0f)));
+    // quadrants: odd ones swap sine and cosine; 2, 3 negate the sine, 1, 2 the cosine (sign bits moved in place)
+    const float s1a = (qa & 1) ? cs.x : sn.x, c1a = (qa & 1) ? sn.x : cs.x;
+    const float s1b = (qb & 1) ? cs.y : sn.y, c1b = (qb & 1) ? sn.y : cs.y;
+    const f32x2 sg = pk2(f32_of(f32_bits(s1a) ^ (((unsigned)qa << 30) & 0x80000000u)), f32_of(f32_bits(s1b) ^ (((unsigned)qb << 30) & 0x80000000u)));
+    const f32x2 cg = pk2(f32_of(f32_bits(c1a) ^ ((((unsigned)qa + 1u) << 30) & 0x80000000u)),
+                         f32_of(f32_bits(c1b) ^ ((((unsigned)qb + 1u) << 30) & 0x80000000u)));
+    const f32x2 mg = pk2(mga, mgb);
+    const f32x2 re = mg * cg, im = mg * sg;
+    A = make_float2(re.x, im.x);
+    B = make_float2(re.y, im.y);
+}
+
 // analysisStep for one bin (Vocoder.hs:158-163).  `prev` is replaced by the new raw phase.
 template <class R>
 VOC_DEV void analyze_bin(const ParamsT<R> &p, int k, cplx<R> X, R &prev, bool emit, R vol, R *mag, R *inc)
@@ -700,6 +844,57 @@ VOC_DEV cplx<R> synthesize_bin(const ParamsT<R> &p, R mag, R inc, R &ph)
     R s, c;
     fast_sincos<LEAN>(ph, &s, &c);
     return mk2(mag * c, mag * s);
+}
+
+// Two bins at a time: the double-precision kernels (and float builds without VOC_F32_PACKED) take the one-bin
+// functions twice, float takes the packed forms above.
+template <bool LEAN>
+VOC_DEV void polar_pair(double2 Xa, double2 Xb, double &ma, double &pa, double &mb, double &pb)
+{
+    hs_polar<LEAN>(Xa.x, Xa.y, ma, pa);
+    hs_polar<LEAN>(Xb.x, Xb.y, mb, pb);
+}
+template <bool LEAN>
+VOC_DEV void polar_pair(float2 Xa, float2 Xb, float &ma, float &pa, float &mb, float &pb)
+{
+    if (VOC_F32_PACKED) {
+        hs_polar_pair(Xa.x, Xa.y, Xb.x, Xb.y, ma, pa, mb, pb);
+    } else {
+        hs_polar<LEAN>(Xa.x, Xa.y, ma, pa);
+        hs_polar<LEAN>(Xb.x, Xb.y, mb, pb);
+    }
+}
+VOC_DEV void inc_pow2_pair(const ParamsT<double> &p, int ka, int kb, double da, double db, double &ia, double &ib)
+{
+    ia = phase_inc_pow2(p, ka, da);
+    ib = phase_inc_pow2(p, kb, db);
+}
+VOC_DEV void inc_pow2_pair(const ParamsT<float> &p, int ka, int kb, float da, float db, float &ia, float &ib)
+{
+    if (VOC_F32_PACKED) {
+        phase_inc_pow2_pair(p, ka, kb, da, db, ia, ib);
+    } else {
+        ia = phase_inc_pow2(p, ka, da);
+        ib = phase_inc_pow2(p, kb, db);
+    }
+}
+template <bool LEAN>
+VOC_DEV void synth_pair(const ParamsT<double> &p, double mga, double ica, double &pha, double mgb, double icb, double &phb,
+                        double2 &A, double2 &B)
+{
+    A = synthesize_bin<double, LEAN>(p, mga, ica, pha);
+    B = synthesize_bin<double, LEAN>(p, mgb, icb, phb);
+}
+template <bool LEAN>
+VOC_DEV void synth_pair(const ParamsT<float> &p, float mga, float ica, float &pha, float mgb, float icb, float &phb,
+                        float2 &A, float2 &B)
+{
+    if (VOC_F32_PACKED) {
+        synthesize_pair(p, mga, ica, pha, mgb, icb, phb, A, B);
+    } else {
+        A = synthesize_bin<float, LEAN>(p, mga, ica, pha);
+        B = synthesize_bin<float, LEAN>(p, mgb, icb, phb);
+    }
 }
 
 // the same with the sine and cosine from the table in LDS (fast_sincos_tab)

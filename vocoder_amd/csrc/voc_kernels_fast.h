@@ -824,14 +824,15 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
                 pb = at_bytes(php, oq, iq);
             }
             R ma, mb, pha, phb;
-            hs_polar<VOC_POLAR_LEAN != 0>(Xa.x, Xa.y, ma, pha);
-            hs_polar<VOC_POLAR_LEAN != 0>(Xb.x, Xb.y, mb, phb);
+            polar_pair<VOC_POLAR_LEAN != 0>(Xa, Xb, ma, pha, mb, phb);
             if (emit) {
                 at_bytes(mrow, ope, ipe) = ma * half_vol;
                 at_bytes(mrow, oq, iq) = mb * half_vol;
                 if constexpr (SLIDE > 0) {  // H = SLIDE * N/8: a power of two, like N
-                    at_bytes(irow, ope, ipe) = phase_inc_pow2(p, pe, pha - pa);
-                    at_bytes(irow, oq, iq) = phase_inc_pow2(p, q, phb - pb);
+                    R ia, ib;
+                    inc_pow2_pair(p, (int)pe, (int)q, pha - pa, phb - pb, ia, ib);
+                    at_bytes(irow, ope, ipe) = ia;
+                    at_bytes(irow, oq, iq) = ib;
                 } else {
                     at_bytes(irow, ope, ipe) = phase_inc(p, pe, pha - pa);
                     at_bytes(irow, oq, iq) = phase_inc(p, q, phb - pb);
@@ -1072,12 +1073,10 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, (syn_fat<LOG2M, OLA, R>() ?
                 A = synthesize_bin_tab(p, mg[2 * m], ic[2 * m], phr[2 * m], col);
                 B = synthesize_bin_tab(p, mg[2 * m + 1], ic[2 * m + 1], phr[2 * m + 1], col);
             } else if constexpr (PHASE_REGS) {
-                A = synthesize_bin<R, LEAN>(p, mg[2 * m], ic[2 * m], phr[2 * m]);
-                B = synthesize_bin<R, LEAN>(p, mg[2 * m + 1], ic[2 * m + 1], phr[2 * m + 1]);
+                synth_pair<LEAN>(p, mg[2 * m], ic[2 * m], phr[2 * m], mg[2 * m + 1], ic[2 * m + 1], phr[2 * m + 1], A, B);
             } else {
                 R pa = php[pe], pb = php[q];
-                A = synthesize_bin<R, LEAN>(p, mg[2 * m], ic[2 * m], pa);
-                B = synthesize_bin<R, LEAN>(p, mg[2 * m + 1], ic[2 * m + 1], pb);
+                synth_pair<LEAN>(p, mg[2 * m], ic[2 * m], pa, mg[2 * m + 1], ic[2 * m + 1], pb, A, B);
                 php[pe] = pa;
                 php[q] = pb;
             }

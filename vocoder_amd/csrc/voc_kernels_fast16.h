@@ -454,14 +454,15 @@ __global__ void __launch_bounds__(Fast16Cfg<LOG2M>::T, (fast16_waves<R, LOG2M>(2
             C2 Xa, Xb;
             split_pair_x2(P, Q, w, Xa, Xb);
             R ma, mb, na, nb;
-            hs_polar<VOC_POLAR_LEAN != 0>(Xa.x, Xa.y, ma, na);
-            hs_polar<VOC_POLAR_LEAN != 0>(Xb.x, Xb.y, mb, nb);
+            polar_pair<VOC_POLAR_LEAN != 0>(Xa, Xb, ma, na, mb, nb);
             if (emit) {
                 at_bytes(mrow, ope, ipe) = ma * half_vol;
                 at_bytes(mrow, oq, iq) = mb * half_vol;
                 if constexpr (SLIDE > 0) {  // H = SLIDE * N/16: a power of two, like N
-                    at_bytes(irow, ope, ipe) = phase_inc_pow2(p, pe, na - pha[m]);
-                    at_bytes(irow, oq, iq) = phase_inc_pow2(p, q, nb - phb[m]);
+                    R ia, ib;
+                    inc_pow2_pair(p, (int)pe, (int)q, na - pha[m], nb - phb[m], ia, ib);
+                    at_bytes(irow, ope, ipe) = ia;
+                    at_bytes(irow, oq, iq) = ib;
                 } else {
                     at_bytes(irow, ope, ipe) = phase_inc(p, pe, na - pha[m]);
                     at_bytes(irow, oq, iq) = phase_inc(p, q, nb - phb[m]);
@@ -617,8 +618,8 @@ __global__ void __launch_bounds__(Fast16Cfg<LOG2M>::T, (fast16_waves<R, LOG2M>(V
         for (int m = 0; m < 8; ++m) {
             const bool self = m == 0 && self0;
             if (m + PF + AHEAD < 8) load_pairs(f, lt, m + PF + AHEAD, m + PF + AHEAD + 1, false);
-            const C2 A = synthesize_bin<R, true>(p, mga[m], ica[m], pha[m]);
-            const C2 B = synthesize_bin<R, true>(p, mgb[m], icb[m], phb[m]);
+            C2 A, B;
+            synth_pair<true>(p, mga[m], ica[m], pha[m], mgb[m], icb[m], phb[m], A, B);
             C2 Za, Zb;
             merge_pair(A, B, split_tw16(tw.s, m, self), Za, Zb);
             za[m] = Za;
