@@ -149,6 +149,19 @@ static int scenario_f32(int n, int h, int channels, int frames)
     OK(voc_stream_get_phases_f32(st, a.data(), s.data()));
     OK(voc_stream_destroy(st));
     OK(voc_filter_destroy(flt));
+    // FFT-compatible layer, step level and addFrames on float data
+    {
+        std::vector<float> fr1((size_t)n, 0.5f), spec((size_t)2 * k), back((size_t)n), p0((size_t)k, 0.f), p1((size_t)k),
+            m1((size_t)k), i1((size_t)k), spec2((size_t)2 * k);
+        fr1[3] = -1.0f;
+        OK(voc_r2c_f32(ctx, fr1.data(), spec.data(), 1));
+        OK(voc_c2r_f32(ctx, spec.data(), back.data(), 1));
+        OK(voc_do_fft_f32(ctx, fr1.data(), spec.data(), 1));
+        OK(voc_analysis_step_f32(ctx, p0.data(), spec.data(), p1.data(), m1.data(), i1.data(), 1));
+        OK(voc_synthesis_step_f32(ctx, p0.data(), m1.data(), i1.data(), p1.data(), spec2.data(), 1));
+        OK(voc_do_ifft_f32(ctx, spec2.data(), back.data(), 1));
+        OK(voc_add_frames_f32(ctx, m1.data(), i1.data(), m1.data(), i1.data(), m1.data(), i1.data(), 1));
+    }
     OK(voc_ctx_destroy(ctx));
     std::printf("ok  f32 N=%d\n", n);
     return 0;
@@ -203,6 +216,10 @@ int main()
     bad |= scenario(4100, 3000, 1000, 1, 3, 1000); // chirp-z through device memory (two interleaved 8192-point transforms)
     bad |= scenario_f32(64, 16, 2, 9);
     bad |= scenario_f32(1024, 256, 1, 7);
+    bad |= scenario(4096, 4096, 1024, 1, 6, 1024);   // sixteen points per thread (analysis), sliding sample window
+    bad |= scenario(4096, 4000, 1000, 1, 4, 1000);   // the same kernels with scalar loads and a padded frame
+    bad |= scenario_f32(4096, 1024, 2, 6);           // sixteen points per thread on float, two bins at a time
+    bad |= scenario(16400, 16400, 4100, 1, 2, 4100); // chirp-z over eight interleaved transforms; rows of 8201 bins: the filter build for long rows
     std::printf(bad ? "FAILURES\n" : "all scenarios ran\n");
     return bad;
 }
