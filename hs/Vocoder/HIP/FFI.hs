@@ -182,6 +182,16 @@ foreign import ccall safe "voc_analysis_stage_f32" c_voc_analysis_stage_f32
     :: Ptr VocCtx -> Ptr Float -> Ptr Float -> Ptr Float -> Ptr Float -> Int64 -> Int64 -> IO Int32
 foreign import ccall safe "voc_synthesis_stage_f32" c_voc_synthesis_stage_f32
     :: Ptr VocCtx -> Ptr Float -> Ptr Float -> Ptr Float -> Ptr Float -> Int64 -> Int64 -> IO Int32
+foreign import ccall safe "voc_r2c_f32"     c_voc_r2c_f32     :: Ptr VocCtx -> Ptr Float -> Ptr Float -> Int64 -> IO Int32
+foreign import ccall safe "voc_c2r_f32"     c_voc_c2r_f32     :: Ptr VocCtx -> Ptr Float -> Ptr Float -> Int64 -> IO Int32
+foreign import ccall safe "voc_do_fft_f32"  c_voc_do_fft_f32  :: Ptr VocCtx -> Ptr Float -> Ptr Float -> Int64 -> IO Int32
+foreign import ccall safe "voc_do_ifft_f32" c_voc_do_ifft_f32 :: Ptr VocCtx -> Ptr Float -> Ptr Float -> Int64 -> IO Int32
+foreign import ccall safe "voc_analysis_step_f32" c_voc_analysis_step_f32
+    :: Ptr VocCtx -> Ptr Float -> Ptr Float -> Ptr Float -> Ptr Float -> Ptr Float -> Int64 -> IO Int32
+foreign import ccall safe "voc_synthesis_step_f32" c_voc_synthesis_step_f32
+    :: Ptr VocCtx -> Ptr Float -> Ptr Float -> Ptr Float -> Ptr Float -> Ptr Float -> Int64 -> IO Int32
+foreign import ccall safe "voc_add_frames_f32" c_voc_add_frames_f32
+    :: Ptr VocCtx -> Ptr Float -> Ptr Float -> Ptr Float -> Ptr Float -> Ptr Float -> Ptr Float -> Int64 -> IO Int32
 foreign import ccall safe "voc_filter_apply_f32" c_voc_filter_apply_f32
     :: Ptr VocFilter -> Ptr Float -> Ptr Float -> Int64 -> Int64 -> IO Int32
 foreign import ccall safe "voc_stream_set_phases_f32" c_voc_stream_set_phases_f32

@@ -440,13 +440,7 @@ int32_t voc_stream_push_dev(voc_stream *s, const double *x, int64_t x_stride, in
 int32_t voc_stream_flush(voc_stream *s, double *y, int64_t y_stride, int64_t y_cap, int64_t *n_out);
 int32_t voc_stream_flush_dev(voc_stream *s, double *y, int64_t y_stride, int64_t y_cap, int64_t *n_out, void *stream);
 
-/* ---- single-precision forms (contexts created with VOC_PRECISION_F32) -------------------------------
- * The stage-level and signal-level entry points on float data: the same arguments as their double
- * forms, every array float.  They run the kernel templates of the fused single-precision round trip
- * (float samples, STFT and phases; the synthesis phase kept wrapped), to that variant's own bar. */
-int32_t voc_analysis_stage_f32(voc_ctx *ctx, float *phase_io, const float *frames, float *mag, float *ph_inc,
-                               int64_t channels, int64_t nframes);
-/* ... and the FFT-compatible layer, the step level and addFrames (voc_r2c, voc_c2r, voc_do_fft, voc_do_ifft,
+/* ---- single-precision forms of the FFT-compatible layer, the step level and addFrames (voc_r2c, voc_c2r, voc_do_fft, voc_do_ifft,
  * voc_analysis_step, voc_synthesis_step, voc_add_frames: Vocoder.hs:143-145,194-196,158-163,186-190,220-222) on
  * float data, for contexts created with VOC_PRECISION_F32: same arguments, every array float (a complex
  * element is two floats, {re, im}); synthesis_step returns its phases wrapped, like every form of the variant. */
@@ -460,6 +454,13 @@ int32_t voc_synthesis_step_f32(voc_ctx *ctx, const float *ph, const float *mag, 
                                float *spec, int64_t batch);
 int32_t voc_add_frames_f32(voc_ctx *ctx, const float *mag1, const float *inc1, const float *mag2, const float *inc2,
                            float *mag_out, float *inc_out, int64_t batch);
+
+/* ---- single-precision forms (contexts created with VOC_PRECISION_F32) -------------------------------
+ * The stage-level and signal-level entry points on float data: the same arguments as their double
+ * forms, every array float.  They run the kernel templates of the fused single-precision round trip
+ * (float samples, STFT and phases; the synthesis phase kept wrapped), to that variant's own bar. */
+int32_t voc_analysis_stage_f32(voc_ctx *ctx, float *phase_io, const float *frames, float *mag, float *ph_inc,
+                               int64_t channels, int64_t nframes);
 int32_t voc_synthesis_stage_f32(voc_ctx *ctx, float *phase_io, const float *mag, const float *ph_inc, float *frames,
                                 int64_t channels, int64_t nframes);
 int32_t voc_analysis_stage_f32_dev(voc_ctx *ctx, float *phase_io, const float *frames, float *mag, float *ph_inc,
