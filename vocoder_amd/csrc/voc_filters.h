@@ -201,13 +201,45 @@ __global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p
                 __syncthreads();
                 break;
             case FOP_ENVELOPE: {  // envelopeFilter (Filter.hs:144-152)
+                const double rs = 1.0 / op.a;
+                const int h = op.len / 2;
+                // Both staging arrays together hold the row of logarithms with its zero margins (the reference
+                // pads the convolved array with len/2 zeros on either side, Filter.hs:132-137), so a tap is one
+                // LDS read and one multiply-add with the kernel value times 1/s -- no bounds test, no division.
+                // (Rows too long for two arrays, or kernels longer than a row, take the term-by-term form.)
+                if (!ONE && op.len <= K) {
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) {
+                        const int k = tid + T * j;
+                        if (k < K) lm[h + k] = log(m[j] + ee);
+                    }
+                    for (int i = tid; i < op.len; i += T) lm[i < h ? i : K + i] = 0.0;  // h in front, len - h behind
+                    __syncthreads();
+                    double acc[NE];
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) acc[j] = 0.0;
+                    const double *row = lm + tid;
+#pragma unroll 4
+                    for (int i = 0; i < op.len; ++i) {
+                        const double kr = op.table[i] * rs;
+#pragma unroll
+                        for (int j = 0; j < NE; ++j)
+                            if (tid + T * j < K) acc[j] = fma(kr, row[T * j + i], acc[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) {
+                        if (tid + T * j < K) m[j] = exp(acc[j]) + (-ee);
+                        ic[j] = 0.0;
+                    }
+                    __syncthreads();
+                    break;
+                }
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
                     const int k = tid + T * j;
                     if (k < K) lm[k] = log(m[j] + ee);
                 }
                 __syncthreads();
-                const double rs = 1.0 / op.a;
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
                     const int k = tid + T * j;
