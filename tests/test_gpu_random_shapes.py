@@ -1,0 +1,84 @@
+"""GPU: a seeded sweep over frame length, window length, hop, channel count, signal length, output chunk and
+tile cuts -- the combinations nobody wrote down by hand.  Every case runs the fused round trip and the stage
+level through the C ABI against the oracle, to the bars of tests/helpers.py (framing, leftover and overlap-add
+bit exact)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import helpers as Hh  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    kind = seed % 4
+    if kind == 0:      # the specialised kernels: W = N, hop a multiple of N/16 (sliding window, register overlap-add)
+        n = int(rng.choice([1024, 2048, 4096, 8192, 16384]))
+        w, h = n, int(n // 16 * rng.choice([1, 2, 4, 8]))
+    elif kind == 1:    # the same lengths with a short window and an arbitrary hop (scalar loads, frames in memory)
+        n = int(rng.choice([1024, 2048, 4096, 8192]))
+        w = int(rng.integers(n // 2, n + 1))
+        h = int(rng.integers(1, w + 1))
+    elif kind == 2:    # small powers of two: the generic kernels
+        n = int(rng.choice([8, 16, 32, 64, 128, 256, 512]))
+        w = int(rng.integers(min(3, n), n + 1))  # (Hann windows of one or two points are all zero: volumeCoeff would be H / 0)
+        h = int(rng.integers(1, w + 1))
+    else:              # any other length: chirp-z in LDS
+        n = int(rng.integers(2, 3000))
+        w = int(rng.integers(min(3, n), n + 1))
+        h = int(rng.integers(1, w + 1))
+    c = int(rng.integers(1, 4))
+    frames = int(rng.integers(0, 14))
+    length = max(0, w + h * (frames - 1) + int(rng.integers(0, h + 1))) if frames else int(rng.integers(0, w))
+    chunk = int(rng.choice([h, 1, 7, w, 1000]))
+    at, st = (0, 0) if rng.integers(0, 2) else (int(rng.integers(1, 9)), int(rng.integers(1, 9)))
+    return n, w, h, c, length, chunk, at, st
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_shapes_against_the_oracle(gpu_lib, orc, seed):
+    n, w, h, c, length, chunk, at, st = _case(seed)
+    rng = np.random.default_rng(seed)
+    Hh.check_roundtrip(gpu_lib, orc, n, w, h, length, c, rng, ana_tile=at, syn_tile=st, chunk=chunk,
+                       kind="tone" if seed % 3 else "noise")
+    f = (length - w) // h + 1 if length >= w else 0
+    if f > 0:
+        Hh.check_stages(gpu_lib, orc, n, w, h, min(f, 6), c, rng, ana_tile=at, syn_tile=st)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_shapes_single_precision(gpu_lib, orc, seed):
+    """The same sweep on single-precision contexts (powers of two only), to the variant's bar against the
+    double-precision oracle; leftover samples bit exact."""
+    from vocoder_amd import vocoder as V, conduit as Cd
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.choice([64, 256, 1024, 2048, 4096, 8192, 16384]))
+    if seed % 2:
+        w, h = n, int(max(1, n // 16) * rng.choice([1, 2, 4, 8]))
+    else:
+        w = int(rng.integers(max(3, n // 2), n + 1))
+        h = int(rng.integers(max(1, w // 8), w + 1))
+    c = int(rng.integers(1, 4))
+    frames = int(rng.integers(1, 14))
+    length = w + h * (frames - 1) + int(rng.integers(0, h + 1))
+    at, st = (0, 0) if rng.integers(0, 2) else (int(rng.integers(1, 9)), int(rng.integers(1, 9)))
+    Hh.set_tiles(at, st)
+    try:
+        win = orc.make_window("hann", w)
+        par = V.VocoderParams(n, h, win, lib=gpu_lib, precision="f32")
+        t = np.arange(length)
+        x = (np.stack([0.5 * np.sin(2 * np.pi * 0.0173 * (i + 1) * t) for i in range(c)]) +
+             0.01 * rng.uniform(-1, 1, (c, length))).astype(np.float32)
+        y, left, _ = Cd.process_with(par, x)
+        for ch in range(c):
+            ref = orc.roundtrip(n, h, win, x[ch].astype(np.float64), h)
+            assert y.shape[1] == ref["y"].size and np.array_equal(left[ch], ref["leftover"].astype(np.float32))
+            assert np.linalg.norm(y[ch] - ref["y"]) <= 2e-4 * np.linalg.norm(ref["y"])
+        par.close()
+    finally:
+        Hh.set_tiles()
