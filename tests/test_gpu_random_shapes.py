@@ -82,3 +82,38 @@ def test_random_shapes_single_precision(gpu_lib, orc, seed):
         par.close()
     finally:
         Hh.set_tiles()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_streams_equal_the_batch_path(gpu_lib, seed):
+    """A stream pushed in random pieces (empty ones included), with initial phases and -- every other case -- a
+    filter chain with a speed change in it, gives the bits of the one-call path on the same context."""
+    import torch
+    from fractions import Fraction
+    from vocoder_amd import vocoder as V, conduit as Cd, stream as S, filter as Fl
+    n, w, h, c, length, chunk, _, _ = _case(seed)
+    if length < w:
+        length = w + 3 * h + 1
+    rng = np.random.default_rng(9000 + seed)
+    length += int(rng.integers(0, 6)) * h
+    par = V.VocoderParams(n, h, np.hanning(w + 2)[1:-1], lib=gpu_lib)
+    x = rng.standard_normal((c, length))
+    cuts = np.concatenate([[0], np.sort(rng.integers(0, length + 1, int(rng.integers(0, 9)))), [length]])
+    if seed % 2 == 0:
+        a0, s0 = rng.uniform(-3, 3, (c, par.K)), rng.uniform(-3, 3, (c, par.K))
+        y_ref, left_ref, (a_ref, s_ref) = Cd.process_with(par, x, phases=(a0, s0), chunk=chunk)
+        st = S.Stream(par, c, chunk, ana_phase=a0, syn_phase=s0)
+        y = np.concatenate([st.push(x[:, a:b]) for a, b in zip(cuts[:-1], cuts[1:])] + [st.flush()], axis=1)
+        assert y.shape == y_ref.shape and np.array_equal(y, y_ref)
+        a, s = st.phases()
+        assert np.array_equal(a, a_ref) and np.array_equal(s, s_ref) and np.array_equal(st.leftover(), left_ref)
+    else:
+        speed = Fraction(int(rng.integers(1, 4)), int(rng.integers(1, 4)))
+        descr = Fl.pitch_shift_interpolate(float(rng.uniform(0.5, 2.0))) >> Fl.play_speed(speed) >> Fl.random_phase_filter(seed)
+        filt = descr.bind(par, 48000.0 / n)
+        y_ref, _, s_ref = Cd.process_filter_dev(par, filt, torch.from_numpy(x).cuda())
+        st = S.Stream(par, c, filt=filt)
+        y = np.concatenate([st.push(x[:, a:b]) for a, b in zip(cuts[:-1], cuts[1:])] + [st.flush()], axis=1)
+        assert np.array_equal(y, y_ref.cpu().numpy())
+        assert np.array_equal(st.phases()[1], s_ref.cpu().numpy())
+    par.close()

@@ -926,7 +926,9 @@ constexpr int syn_lds_bytes()
 // pairs per frame.  y rows must be 16-byte aligned.
 // MAPPED: rows are looked up through a.mag_rows / a.inc_rows (a build of its own: the lookups cost
 // the unmapped path 1 % when they are decided at run time).
-template <int LOG2M, bool OLA, int NHP, class R = double, bool MAPPED = false>
+// ALIGNED = false: the output rows are not 16-byte aligned (an odd row stride or base): the emitted sample pairs
+// are stored as two 8-byte values each.  Same arithmetic: which build runs does not change a bit of the result.
+template <int LOG2M, bool OLA, int NHP, class R = double, bool MAPPED = false, bool ALIGNED = true>
 __global__ void __launch_bounds__(FastCfg<LOG2M>::T, (syn_fat<LOG2M, OLA, R>() ? 2 : VOC_FAST_WAVES)) synthesis_fast_kernel(ParamsT<R> p, SynArgsT<R> a)
 {
     using C2 = cplx<R>;
@@ -1182,9 +1184,18 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, (syn_fat<LOG2M, OLA, R>() ?
 #pragma unroll
             for (int j = 0; j < NHP; ++j) opaque(cur[j]);
             if (emit) {
-                C2 *yc = reinterpret_cast<C2 *>(a.out + c * a.out_stride + f * p.H);
+                if constexpr (ALIGNED) {
+                    C2 *yc = reinterpret_cast<C2 *>(a.out + c * a.out_stride + f * p.H);
 #pragma unroll
-                for (int j = 0; j < NHP; ++j) at_bytes(yc + j * T, lane16, 0) = cur[j];
+                    for (int j = 0; j < NHP; ++j) at_bytes(yc + j * T, lane16, 0) = cur[j];
+                } else {
+                    R *ys = a.out + c * a.out_stride + f * p.H + 2 * lt;
+#pragma unroll
+                    for (int j = 0; j < NHP; ++j) {
+                        ys[2 * j * T] = cur[j].x;
+                        ys[2 * j * T + 1] = cur[j].y;
+                    }
+                }
             }
 #pragma unroll
             for (int j = 0; j < NK; ++j) tail[j] = cur[j + NHP];

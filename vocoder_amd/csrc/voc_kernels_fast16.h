@@ -525,10 +525,11 @@ __global__ void __launch_bounds__(Fast16Cfg<LOG2M>::T, (fast16_waves<R, LOG2M>(2
 #define VOC_SYN16_WIN_AHEAD 2  // synthesis: steps (of four) of the overlap-add whose window values are in flight ahead of their use
 #endif
 
-// Synthesis with the overlap-add in registers.  Requires W == N, H = NHP * 2T and 16-byte aligned y rows:
+// Synthesis with the overlap-add in registers.  Requires W == N and H = NHP * 2T (ALIGNED: 16-byte aligned y rows;
+// otherwise the emitted pairs are stored as two values each):
 // thread t owns the sample PAIRS 2 (t + j T), + 1, j = 0..15, of the window, and the partial sums shift by
 // NHP pair slots per frame.
-template <int LOG2M, int NHP, class R = double, bool MAPPED = false>
+template <int LOG2M, int NHP, class R = double, bool MAPPED = false, bool ALIGNED = true>
 __global__ void __launch_bounds__(Fast16Cfg<LOG2M>::T, (fast16_waves<R, LOG2M>(VOC_SYN16_WAVES, VOC_F32_SYN16_WAVES))) synthesis_fast16_kernel(ParamsT<R> p, SynArgsT<R> a)
 {
     using C2 = cplx<R>;
@@ -686,9 +687,18 @@ __global__ void __launch_bounds__(Fast16Cfg<LOG2M>::T, (fast16_waves<R, LOG2M>(V
 #pragma unroll
         for (int j = 0; j < NHP; ++j) opaque(out[j]);
         if (emit) {
-            C2 *yc = reinterpret_cast<C2 *>(a.out + c * a.out_stride + f * p.H);
+            if constexpr (ALIGNED) {
+                C2 *yc = reinterpret_cast<C2 *>(a.out + c * a.out_stride + f * p.H);
 #pragma unroll
-            for (int j = 0; j < NHP; ++j) at_bytes(yc + j * T, lane16, 0) = out[j];
+                for (int j = 0; j < NHP; ++j) at_bytes(yc + j * T, lane16, 0) = out[j];
+            } else {  // rows that are not 16-byte aligned: the pairs as two values each
+                R *ys = a.out + c * a.out_stride + f * p.H + 2 * lt;
+#pragma unroll
+                for (int j = 0; j < NHP; ++j) {
+                    ys[2 * j * T] = out[j].x;
+                    ys[2 * j * T + 1] = out[j].y;
+                }
+            }
         }
         mark(10);
         __syncthreads();  // the transform's LDS area is rewritten by the next frame's spectrum

@@ -614,18 +614,26 @@ void launch_analysis_fast16(voc_ctx *c, const voc::AnaArgsT<R> &a, unsigned grid
     else hipLaunchKernelGGL((voc::analysis_fast16_kernel<L, true, 0, R>), g, b, lds, st, p, a);
 }
 
-template <int L, bool MAPPED, class R>
-void launch_synthesis_fast16(voc_ctx *c, const voc::SynArgsT<R> &a, unsigned grid, int nhp, hipStream_t st)
+template <int L, bool MAPPED, class R, bool ALIGNED>
+void launch_synthesis_fast16_al(voc_ctx *c, const voc::SynArgsT<R> &a, unsigned grid, int nhp, hipStream_t st)
 {
     const dim3 g(grid), b(voc::Fast16Cfg<L>::T);
     const size_t lds = voc::Fast16Cfg<L>::template lds_bytes<R>();
     const voc::ParamsT<R> &p = params_of<R>(c);
     switch (nhp) {
-    case 1: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 1, R, MAPPED>), g, b, lds, st, p, a); break;
-    case 2: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 2, R, MAPPED>), g, b, lds, st, p, a); break;
-    case 4: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 4, R, MAPPED>), g, b, lds, st, p, a); break;
-    default: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 8, R, MAPPED>), g, b, lds, st, p, a); break;
+    case 1: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 1, R, MAPPED, ALIGNED>), g, b, lds, st, p, a); break;
+    case 2: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 2, R, MAPPED, ALIGNED>), g, b, lds, st, p, a); break;
+    case 4: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 4, R, MAPPED, ALIGNED>), g, b, lds, st, p, a); break;
+    default: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 8, R, MAPPED, ALIGNED>), g, b, lds, st, p, a); break;
     }
+}
+
+// (output rows that are not 16-byte aligned take the build that stores the sample pairs as two values each)
+template <int L, bool MAPPED, class R>
+void launch_synthesis_fast16(voc_ctx *c, const voc::SynArgsT<R> &a, unsigned grid, int nhp, hipStream_t st)
+{
+    if (rows_aligned16(a.out, a.out_stride)) launch_synthesis_fast16_al<L, MAPPED, R, true>(c, a, grid, nhp, st);
+    else launch_synthesis_fast16_al<L, MAPPED, R, false>(c, a, grid, nhp, st);
 }
 
 #if defined(VOC_STAMPS) && !defined(VOC_EMU)
@@ -702,30 +710,38 @@ bool launch_analysis_fast(voc_ctx *c, const voc::AnaArgsT<R> &a, long long chann
     return true;
 }
 
-// The register-resident overlap-add needs W == N (eight sample pairs per thread), a hop that is a
-// multiple of twice the thread count, and 16-byte aligned output rows.  Returns H / 2T or 0.
+// The register-resident overlap-add needs W == N (eight sample pairs per thread) and a hop that is a
+// multiple of twice the thread count.  Returns H / 2T or 0.  It depends on the context alone: whatever the
+// alignment of a call's output rows, the same kernel arithmetic runs (16-byte or 8-byte stores), so that every
+// entry point of a context gives the same bits.
 template <class R>
-inline int fast_ola_nhp(const voc_ctx *c, const voc::SynArgsT<R> &a)
+inline int fast_ola_nhp(const voc_ctx *c, const voc::SynArgsT<R> &)
 {
     if (!fast_sizes(c) || c->W != c->N) return 0;
     const int t2 = 2 * (c->M / 8);
     if (c->H % t2 != 0) return 0;
-    if (reinterpret_cast<uintptr_t>(a.out) % (2 * sizeof(R)) != 0 || a.out_stride % 2 != 0) return 0;
     const int nhp = c->H / t2;
     return (nhp == 1 || nhp == 2 || nhp == 4 || nhp == 8) ? nhp : 0;
+}
+
+template <int L, bool OLA, class R, bool MAPPED, bool ALIGNED>
+void launch_synthesis_fast_al(voc_ctx *c, const voc::SynArgsT<R> &a, unsigned grid, int nhp, hipStream_t st)
+{
+    const dim3 g(grid), b(voc::FastCfg<L>::T);
+    const size_t lds = voc::syn_lds_bytes<L, OLA, R>();
+    switch (nhp) {
+    case 1: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 1, R, MAPPED, ALIGNED>), g, b, lds, st, params_of<R>(c), a); break;
+    case 2: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 2, R, MAPPED, ALIGNED>), g, b, lds, st, params_of<R>(c), a); break;
+    case 4: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 4, R, MAPPED, ALIGNED>), g, b, lds, st, params_of<R>(c), a); break;
+    default: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 8, R, MAPPED, ALIGNED>), g, b, lds, st, params_of<R>(c), a); break;
+    }
 }
 
 template <int L, bool OLA, class R, bool MAPPED = false>
 void launch_synthesis_fast_nh(voc_ctx *c, const voc::SynArgsT<R> &a, unsigned grid, int nhp, hipStream_t st)
 {
-    const dim3 g(grid), b(voc::FastCfg<L>::T);
-    const size_t lds = voc::syn_lds_bytes<L, OLA, R>();
-    switch (nhp) {
-    case 1: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 1, R, MAPPED>), g, b, lds, st, params_of<R>(c), a); break;
-    case 2: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 2, R, MAPPED>), g, b, lds, st, params_of<R>(c), a); break;
-    case 4: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 4, R, MAPPED>), g, b, lds, st, params_of<R>(c), a); break;
-    default: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, OLA, 8, R, MAPPED>), g, b, lds, st, params_of<R>(c), a); break;
-    }
+    if (!OLA || rows_aligned16(a.out, a.out_stride)) launch_synthesis_fast_al<L, OLA, R, MAPPED, true>(c, a, grid, nhp, st);
+    else launch_synthesis_fast_al<L, OLA, R, MAPPED, false>(c, a, grid, nhp, st);
 }
 
 // (the mapped build exists for double only; this keeps the float instantiation of the launcher well formed)
@@ -736,7 +752,7 @@ inline voc::SynArgsT<double> as_double_args(const voc::SynArgsT<float> &) { retu
 template <class R>
 bool launch_synthesis_fast(voc_ctx *c, const voc::SynArgsT<R> &a, long long channels, bool ola, hipStream_t st)
 {
-    const int s16 = (ola && rows_aligned16(a.out, a.out_stride)) ? fast16_hop_slots(c, true) : 0;
+    const int s16 = ola ? fast16_hop_slots(c, true) : 0;
     if (!fast_sizes(c) && s16 == 0) return false;
     const int nh = ola ? fast_ola_nhp(c, a) : 8;
     if (ola && nh == 0 && s16 == 0) return false;
@@ -980,7 +996,7 @@ void synthesis_signal_dev(voc_ctx *c, const R *mag, const R *inc, long long ldk,
     if (C <= 0 || F <= 0) return;
     WsUse use(c, st);
     const bool fused = !c->bluestein && (lds_bytes<R>(c, true) <= kLdsLimit ||
-                                         (fast16_hop_slots(c, true) > 0 && rows_aligned16(y, y_stride)));
+                                         fast16_hop_slots(c, true) > 0);
     const int halo = fused ? (c->W + c->H - 1) / c->H - 1 : 0;
     int tile_len, tiles;
     synthesis_tiling(c, C, F, halo, &tile_len, &tiles);
@@ -1149,7 +1165,7 @@ void roundtrip_dev(voc_ctx *c, const R *x, long long x_stride, long long len, lo
                                 hipMemcpyDeviceToDevice, st));
     if (F <= 0) return;
 
-    const bool ola16 = fast16_hop_slots(c, true) > 0 && rows_aligned16(y, y_stride);
+    const bool ola16 = fast16_hop_slots(c, true) > 0;
     // channels per pass: as many as the workspace holds
     long long group = C;
     std::optional<WsUse> own;  // the library's own workspace is shared between calls; a caller's is the caller's to order
