@@ -117,3 +117,47 @@ def test_random_streams_equal_the_batch_path(gpu_lib, seed):
         assert np.array_equal(y, y_ref.cpu().numpy())
         assert np.array_equal(st.phases()[1], s_ref.cpu().numpy())
     par.close()
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("seed", range(24))
+def test_random_device_layouts_give_the_bits_of_the_host_call(gpu_lib, seed, precision):
+    """Device-resident calls whose rows start at odd element offsets, with odd row strides and a caller workspace
+    too small for all channels at once, give the bits of the host-pointer call: which kernel a context runs depends
+    on the context alone, never on a call's alignment, strides or grouping."""
+    import torch
+    from vocoder_amd import vocoder as V, conduit as Cd
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.choice([256, 1024, 2048, 4096, 8192, 16384]))
+    if seed % 3:
+        w, h = n, int(max(1, n // 16) * rng.choice([1, 2, 4, 8]))
+    else:
+        w = int(rng.integers(n // 2, n + 1))
+        h = int(rng.integers(max(1, w // 6), w + 1))
+    c = int(rng.integers(2, 6))
+    frames = int(rng.integers(1, 12))
+    length = w + h * (frames - 1) + int(rng.integers(0, h + 1))
+    chunk = int(rng.choice([h, 1, 7, 1000]))
+    par = V.VocoderParams(n, h, np.hanning(w + 2)[1:-1], lib=gpu_lib, precision=precision)
+    npdt, tdt = (np.float32, torch.float32) if precision == "f32" else (np.float64, torch.float64)
+    x = rng.standard_normal((c, length)).astype(npdt)
+    a0, s0 = rng.uniform(-3, 3, (c, par.K)).astype(npdt), rng.uniform(-3, 3, (c, par.K)).astype(npdt)
+    y_ref, left_ref, (a_ref, s_ref) = Cd.process_with(par, x, phases=(a0, s0), chunk=chunk)
+    # rows at an odd element offset inside a wider buffer with an odd stride
+    xs, ys = length + 1 + 2 * int(rng.integers(0, 3)), y_ref.shape[1] + 1 + 2 * int(rng.integers(0, 3))
+    xb = torch.zeros(c * xs + 1, dtype=tdt, device="cuda")
+    yb = torch.full((c * ys + 1,), 7.0, dtype=tdt, device="cuda")
+    xv = xb[1:].view(c, xs)[:, :length]
+    yv = yb[1:].view(c, ys)[:, :y_ref.shape[1]]
+    xv.copy_(torch.from_numpy(x))
+    aph, sph = torch.from_numpy(a0).cuda(), torch.from_numpy(s0).cuda()
+    left = torch.empty((c, max(left_ref.shape[1], 1)), dtype=tdt, device="cuda")
+    full = Cd.roundtrip_workspace_bytes(par, length, c)
+    ws = torch.empty(max(full * 2 // c, 1024) if seed % 2 else full, dtype=torch.uint8, device="cuda")   # odd seeds: room for two channels
+    Cd.process_dev(par, xv, yv, aph, sph, length=length, chunk=chunk, leftover=left, workspace=ws)
+    torch.cuda.synchronize()
+    assert np.array_equal(yv.cpu().numpy(), y_ref)
+    assert np.array_equal(aph.cpu().numpy(), a_ref) and np.array_equal(sph.cpu().numpy(), s_ref)
+    assert np.array_equal(left.cpu().numpy()[:, :left_ref.shape[1]], left_ref)
+    assert float(yb[0]) == 7.0 and bool((yb[1:].view(c, ys)[:, y_ref.shape[1]:] == 7.0).all())   # nothing outside the rows is written
+    par.close()

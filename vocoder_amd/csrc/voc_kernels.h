@@ -763,7 +763,7 @@ VOC_DEV void phase_inc_pow2_pair(const ParamsT<float> &p, int ka, int kb, float 
 {
     const f32x2 kf = pk2((float)ka, (float)kb), km = pk2((float)(ka & p.turn_mask), (float)(kb & p.turn_mask));
     const f32x2 hi = splat2(uniform_f(p.om1_hi));
-    const f32x2 x = fma2(-km, hi, pk2(da, db));                                    // ph_diff - (k mod N/H) omega1
+    const f32x2 x = pk2(da, db) - km * hi;                                         // ph_diff - (k mod N/H) omega1: product, then difference, as phase_inc_pow2
     const f32x2 u = (x + splat2(kPiF)) * splat2(kInvTwoPiF);
     const f32x2 n = pk2(floorf(u.x), floorf(u.y));
     const f32x2 w = fma2(-n, splat2(kTwoPiLoF), fma2(-n, splat2(kTwoPiHiF), x));   // wrap_floor_f
