@@ -161,3 +161,31 @@ def test_random_device_layouts_give_the_bits_of_the_host_call(gpu_lib, seed, pre
     assert np.array_equal(left.cpu().numpy()[:, :left_ref.shape[1]], left_ref)
     assert float(yb[0]) == 7.0 and bool((yb[1:].view(c, ys)[:, y_ref.shape[1]:] == 7.0).all())   # nothing outside the rows is written
     par.close()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_stage_level_equals_the_fused_call(gpu_lib, seed):
+    """framesOfE -> analysisStage -> volumeFix -> synthesisStage -> sumFramesE through the stage-level entry points
+    gives the bits of the fused call, whatever kernels each of them runs (frames in memory against frames cut in
+    place, overlap-add in memory against overlap-add in registers)."""
+    from vocoder_amd import vocoder as V, conduit as Cd
+    n, w, h, c, length, chunk, at, st = _case(seed)
+    if length < w:
+        length = w + 2 * h
+    rng = np.random.default_rng(3000 + seed)
+    Hh.set_tiles(at, st)
+    try:
+        par = V.VocoderParams(n, h, np.hanning(w + 2)[1:-1], lib=gpu_lib)
+        x = rng.standard_normal((c, length))
+        a0, s0 = rng.uniform(-3, 3, (c, par.K)), rng.uniform(-3, 3, (c, par.K))
+        y_ref, left_ref, (a_ref, s_ref) = Cd.process_with(par, x, phases=(a0, s0), chunk=chunk)
+        frames, left = Cd.frames_of_e(par, x)
+        aph, (mag, inc) = V.analysis_stage(par, a0, frames)
+        mag = mag * par.lib.dll.voc_volume_coeff(par.handle)               # volumeFix (Conduit.hs:34-35)
+        sph, out = V.synthesis_stage(par, s0, (mag, inc))
+        y = Cd.sum_frames_e(par, out, chunk)
+        assert np.array_equal(left, left_ref) and np.array_equal(aph, a_ref) and np.array_equal(sph, s_ref)
+        assert y.shape == y_ref.shape and np.array_equal(y, y_ref)
+        par.close()
+    finally:
+        Hh.set_tiles()

@@ -535,6 +535,7 @@ __global__ void __launch_bounds__(Fast16Cfg<LOG2M>::T, (fast16_waves<R, LOG2M>(V
     using C2 = cplx<R>;
     constexpr int M = Fast16Cfg<LOG2M>::M, T = Fast16Cfg<LOG2M>::T;
     constexpr int NP = 16;                 // sample pairs per thread
+    constexpr bool FRAMES = NHP == 16;     // no overlap-add: every frame is written whole, [C][F][W] (synthesisStage)
     constexpr int NK = NP - NHP;           // pairs whose partial sums outlive the frame
     constexpr int NT = NK > 0 ? NK : 1;
     VOC_SMEM(C2, lds);
@@ -545,7 +546,7 @@ __global__ void __launch_bounds__(Fast16Cfg<LOG2M>::T, (fast16_waves<R, LOG2M>(V
     const int tile = whole ? 0 : (int)(rest % a.tiles);
     const long long f0 = (long long)tile * a.tile_len;
     const long long f1 = (whole || f0 + a.tile_len >= a.F) ? a.F : f0 + a.tile_len;
-    const long long halo = (long long)a.halo < f0 ? (long long)a.halo : f0;
+    const long long halo = FRAMES ? 0 : ((long long)a.halo < f0 ? (long long)a.halo : f0);
     const long long fs = f0 - halo;
 
     // accumulated phases of the thread's eight bin pairs, and of DC / Nyquist in thread 0
@@ -687,12 +688,13 @@ __global__ void __launch_bounds__(Fast16Cfg<LOG2M>::T, (fast16_waves<R, LOG2M>(V
 #pragma unroll
         for (int j = 0; j < NHP; ++j) opaque(out[j]);
         if (emit) {
+            R *dst = FRAMES ? a.out + (c * a.F + f) * p.W : a.out + c * a.out_stride + f * p.H;
             if constexpr (ALIGNED) {
-                C2 *yc = reinterpret_cast<C2 *>(a.out + c * a.out_stride + f * p.H);
+                C2 *yc = reinterpret_cast<C2 *>(dst);
 #pragma unroll
                 for (int j = 0; j < NHP; ++j) at_bytes(yc + j * T, lane16, 0) = out[j];
             } else {  // rows that are not 16-byte aligned: the pairs as two values each
-                R *ys = a.out + c * a.out_stride + f * p.H + 2 * lt;
+                R *ys = dst + 2 * lt;
 #pragma unroll
                 for (int j = 0; j < NHP; ++j) {
                     ys[2 * j * T] = out[j].x;
@@ -720,15 +722,17 @@ __global__ void __launch_bounds__(Fast16Cfg<LOG2M>::T, (fast16_waves<R, LOG2M>(V
         }
         // tail after the last frame: the remaining N - H partial sums, then the zero padding of the last
         // chunk (sumFramesE, Frames.hs:45-47)
-        R *yc = a.out + c * a.out_stride;
-        const long long start = a.F * p.H;
+        if constexpr (!FRAMES) {
+            R *yc = a.out + c * a.out_stride;
+            const long long start = a.F * p.H;
 #pragma unroll
-        for (int j = 0; j < NK; ++j) {
-            const long long pos = start + 2 * (tid + j * T);
-            if (pos < a.out_len) yc[pos] = tail[j].x;
-            if (pos + 1 < a.out_len) yc[pos + 1] = tail[j].y;
+            for (int j = 0; j < NK; ++j) {
+                const long long pos = start + 2 * (tid + j * T);
+                if (pos < a.out_len) yc[pos] = tail[j].x;
+                if (pos + 1 < a.out_len) yc[pos + 1] = tail[j].y;
+            }
+            for (long long pos = start + 2 * NK * T + tid; pos < a.out_len; pos += T) yc[pos] = (R)0;
         }
-        for (long long pos = start + 2 * NK * T + tid; pos < a.out_len; pos += T) yc[pos] = (R)0;
     }
 }
 

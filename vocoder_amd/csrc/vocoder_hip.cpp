@@ -624,7 +624,10 @@ void launch_synthesis_fast16_al(voc_ctx *c, const voc::SynArgsT<R> &a, unsigned 
     case 1: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 1, R, MAPPED, ALIGNED>), g, b, lds, st, p, a); break;
     case 2: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 2, R, MAPPED, ALIGNED>), g, b, lds, st, p, a); break;
     case 4: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 4, R, MAPPED, ALIGNED>), g, b, lds, st, p, a); break;
-    default: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 8, R, MAPPED, ALIGNED>), g, b, lds, st, p, a); break;
+    case 8: hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 8, R, MAPPED, ALIGNED>), g, b, lds, st, p, a); break;
+    default:  // 16: whole frames out, no overlap-add
+        if constexpr (!MAPPED) hipLaunchKernelGGL((voc::synthesis_fast16_kernel<L, 16, R, false, ALIGNED>), g, b, lds, st, p, a);
+        break;
     }
 }
 
@@ -632,7 +635,9 @@ void launch_synthesis_fast16_al(voc_ctx *c, const voc::SynArgsT<R> &a, unsigned 
 template <int L, bool MAPPED, class R>
 void launch_synthesis_fast16(voc_ctx *c, const voc::SynArgsT<R> &a, unsigned grid, int nhp, hipStream_t st)
 {
-    if (rows_aligned16(a.out, a.out_stride)) launch_synthesis_fast16_al<L, MAPPED, R, true>(c, a, grid, nhp, st);
+    // (whole frames out: rows of W = N samples, aligned with their base)
+    const bool aligned = nhp == 16 ? rows_aligned16(a.out, 0) : rows_aligned16(a.out, a.out_stride);
+    if (aligned) launch_synthesis_fast16_al<L, MAPPED, R, true>(c, a, grid, nhp, st);
     else launch_synthesis_fast16_al<L, MAPPED, R, false>(c, a, grid, nhp, st);
 }
 
@@ -752,10 +757,14 @@ inline voc::SynArgsT<double> as_double_args(const voc::SynArgsT<float> &) { retu
 template <class R>
 bool launch_synthesis_fast(voc_ctx *c, const voc::SynArgsT<R> &a, long long channels, bool ola, hipStream_t st)
 {
-    const int s16 = ola ? fast16_hop_slots(c, true) : 0;
-    if (!fast_sizes(c) && s16 == 0) return false;
-    const int nh = ola ? fast_ola_nhp(c, a) : 8;
-    if (ola && nh == 0 && s16 == 0) return false;
+    // Whether a context's synthesis takes the specialised kernels depends on the context alone, and is the same
+    // for frames out (synthesisStage) and overlap-add out (the fused call, streams): a context whose overlap-add
+    // form has no specialised build (W < N, a hop that is no multiple of the pair slots) takes the generic kernels
+    // for both, so that the stage-level chain and the fused call give the same bits.
+    const int s16 = fast16_hop_slots(c, true);
+    const int nh_ctx = fast_ola_nhp(c, a);
+    if (s16 == 0 && nh_ctx == 0) return false;
+    const int nh = ola ? nh_ctx : 8;
     const bool mapped = a.mag_rows || a.inc_rows;
     if (mapped && !(ola && std::is_same<R, double>::value)) return false;  // the generic kernel reads through maps too
     const long long grid = a.unsplit + (channels - a.unsplit) * a.tiles;
@@ -767,7 +776,7 @@ bool launch_synthesis_fast(voc_ctx *c, const voc::SynArgsT<R> &a, long long chan
 #define X(L)                                                                                                     \
     case L:                                                                                                      \
         if (mapped) launch_synthesis_fast16<L, true, double>(c, as_double_args(a), (unsigned)grid, s16, st);      \
-        else launch_synthesis_fast16<L, false, R>(c, a, (unsigned)grid, s16, st);                                \
+        else launch_synthesis_fast16<L, false, R>(c, a, (unsigned)grid, ola ? s16 : 16, st);                     \
         break;
             VOC_FOR_EACH_FAST16_LOG2M(X)
 #undef X
