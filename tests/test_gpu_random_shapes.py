@@ -189,3 +189,102 @@ def test_random_stage_level_equals_the_fused_call(gpu_lib, seed):
         par.close()
     finally:
         Hh.set_tiles()
+
+
+def _random_chain(rng):
+    ops = []
+    for _ in range(int(rng.integers(1, 6))):
+        kind = int(rng.integers(0, 9))
+        lo, hi = sorted(rng.uniform(50.0, 20000.0, 2))
+        if kind == 0:
+            ops.append(("amplify", float(rng.uniform(0.1, 3.0))))
+        elif kind == 1:
+            ops.append((str(rng.choice(["lowpass_brickwall", "highpass_brickwall"])), float(lo)))
+        elif kind == 2:
+            ops.append((str(rng.choice(["bandpass_brickwall", "bandstop_brickwall"])), float(lo), float(hi)))
+        elif kind == 3:
+            ops.append((str(rng.choice(["lowpass_butterworth", "highpass_butterworth"])), float(rng.integers(1, 5)), float(lo)))
+        elif kind == 4:
+            ops.append((str(rng.choice(["bandpass_butterworth", "bandstop_butterworth"])), float(rng.integers(1, 4)), float(lo), float(hi)))
+        elif kind == 5:
+            ops.append(("pitch_shift", float(rng.uniform(0.4, 2.5))))
+        elif kind == 6:
+            ops.append(("convolution", tuple(rng.uniform(0.1, 1.0, int(rng.integers(1, 12))))))
+        elif kind == 7:
+            ops.append(("envelope", int(rng.integers(1, 40))))
+        else:
+            ops.append(("pitch_shift", float(rng.choice([0.5, 2.0]))))
+    return ops
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_filter_chains_against_the_filter_oracle(gpu_lib, orc, seed):
+    """Random chains of the per-frame filters (Filter.hs) on STFTs of random frame lengths, channel and frame counts,
+    rows padded to an even length: bit exact against the filter oracle, except behind an envelope stage (log / exp)."""
+    import torch
+    from vocoder_amd import vocoder as V, filter as Fl
+    rng = np.random.default_rng(11000 + seed)
+    n = int(rng.choice([16, 64, 100, 1000, 1024, 3000, 4096, 8192, 16384, 20000])) if seed % 8 else 32768
+    par = V.VocoderParams(n, max(1, n // 4), np.hanning(n + 2)[1:-1], lib=gpu_lib)
+    chain = _random_chain(rng)
+    f = Fl.id_filter()
+    for name, *prm in chain:
+        fn = {"pitch_shift": Fl.pitch_shift_interpolate, "convolution": Fl.convolution_filter,
+              "envelope": Fl.envelope_filter}.get(name) or getattr(Fl, name)
+        f = f >> fn(*prm)
+    step = 48000.0 / n
+    c, nf = int(rng.integers(1, 4)), int(rng.integers(1, 6))
+    ldk = (par.K + 1) & ~1
+    mag, inc = rng.uniform(0, 1, (c, nf, ldk)), rng.uniform(-1, 1, (c, nf, ldk))
+    m, i = f.bind(par, step).apply_dev(torch.from_numpy(mag).cuda(), torch.from_numpy(inc).cuda())
+    torch.cuda.synchronize()
+    m, i = m.cpu().numpy(), i.cpu().numpy()
+    chain_o = [(nm, np.array(p[0])) if nm == "convolution" else (nm, *p) for nm, *p in chain]
+    mo, io = orc.apply_filter(step, chain_o, mag[..., :par.K], inc[..., :par.K])
+    if any(s[0] == "envelope" for s in chain):
+        assert np.allclose(m[..., :par.K], mo, rtol=1e-11, atol=1e-14)
+    else:
+        assert np.array_equal(m[..., :par.K], mo)
+    assert np.array_equal(i[..., :par.K], io)
+    assert np.array_equal(m[..., par.K:], mag[..., par.K:]) and np.array_equal(i[..., par.K:], inc[..., par.K:])
+    par.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_streams_single_precision(gpu_lib, seed):
+    """The stream sweep on single-precision contexts: float state, the bits of the float one-call path."""
+    import torch
+    from fractions import Fraction
+    from vocoder_amd import vocoder as V, conduit as Cd, stream as S, filter as Fl
+    rng = np.random.default_rng(13000 + seed)
+    n = int(rng.choice([64, 1024, 4096, 8192, 16384]))
+    if seed % 3:
+        w, h = n, int(max(1, n // 16) * rng.choice([1, 2, 4, 8]))
+    else:
+        w = int(rng.integers(max(3, n // 2), n + 1))
+        h = int(rng.integers(max(1, w // 6), w + 1))
+    c = int(rng.integers(1, 4))
+    length = w + h * int(rng.integers(2, 12)) + int(rng.integers(0, h + 1))
+    chunk = int(rng.choice([h, 1, 7, 1000]))
+    par = V.VocoderParams(n, h, np.hanning(w + 2)[1:-1], lib=gpu_lib, precision="f32")
+    x = rng.standard_normal((c, length)).astype(np.float32)
+    cuts = np.concatenate([[0], np.sort(rng.integers(0, length + 1, int(rng.integers(0, 9)))), [length]])
+    if seed % 2 == 0:
+        a0 = rng.uniform(-3, 3, (c, par.K)).astype(np.float32)
+        s0 = rng.uniform(-3, 3, (c, par.K)).astype(np.float32)
+        y_ref, left_ref, (a_ref, s_ref) = Cd.process_with(par, x, phases=(a0, s0), chunk=chunk)
+        st = S.Stream(par, c, chunk, ana_phase=a0, syn_phase=s0)
+        y = np.concatenate([st.push(x[:, a:b]) for a, b in zip(cuts[:-1], cuts[1:])] + [st.flush()], axis=1)
+        assert y.dtype == np.float32 and y.shape == y_ref.shape and np.array_equal(y, y_ref)
+        a, s = st.phases()
+        assert np.array_equal(a, a_ref) and np.array_equal(s, s_ref) and np.array_equal(st.leftover(), left_ref)
+    else:
+        speed = Fraction(int(rng.integers(1, 4)), int(rng.integers(1, 4)))
+        descr = Fl.lowpass_butterworth(2.0, 4000.0) >> Fl.play_speed(speed) >> Fl.random_phase_filter(seed)
+        filt = descr.bind(par, 48000.0 / n)
+        y_ref, _, s_ref = Cd.process_filter_dev(par, filt, torch.from_numpy(x).cuda())
+        st = S.Stream(par, c, filt=filt)
+        y = np.concatenate([st.push(x[:, a:b]) for a, b in zip(cuts[:-1], cuts[1:])] + [st.flush()], axis=1)
+        assert np.array_equal(y, y_ref.cpu().numpy())
+        assert np.array_equal(st.phases()[1], s_ref.cpu().numpy())
+    par.close()

@@ -749,10 +749,6 @@ void launch_synthesis_fast_nh(voc_ctx *c, const voc::SynArgsT<R> &a, unsigned gr
     else launch_synthesis_fast_al<L, OLA, R, MAPPED, false>(c, a, grid, nhp, st);
 }
 
-// (the mapped build exists for double only; this keeps the float instantiation of the launcher well formed)
-inline const voc::SynArgsT<double> &as_double_args(const voc::SynArgsT<double> &a) { return a; }
-inline voc::SynArgsT<double> as_double_args(const voc::SynArgsT<float> &) { return voc::SynArgsT<double>{}; }
-
 // Specialised synthesis kernel (polar input): frames out, or overlap-add out when fast_ola_nhp() != 0.
 template <class R>
 bool launch_synthesis_fast(voc_ctx *c, const voc::SynArgsT<R> &a, long long channels, bool ola, hipStream_t st)
@@ -766,7 +762,7 @@ bool launch_synthesis_fast(voc_ctx *c, const voc::SynArgsT<R> &a, long long chan
     if (s16 == 0 && nh_ctx == 0) return false;
     const int nh = ola ? nh_ctx : 8;
     const bool mapped = a.mag_rows || a.inc_rows;
-    if (mapped && !(ola && std::is_same<R, double>::value)) return false;  // the generic kernel reads through maps too
+    if (mapped && !ola) return false;  // (frames out through row maps: the generic kernel reads through maps too)
     const long long grid = a.unsplit + (channels - a.unsplit) * a.tiles;
     if (grid <= 0) return true;
     if (grid > 0x7fffffffLL) throw HipFail{hipErrorInvalidValue, "synthesis grid too large"};
@@ -775,7 +771,7 @@ bool launch_synthesis_fast(voc_ctx *c, const voc::SynArgsT<R> &a, long long chan
         switch (c->log2m) {
 #define X(L)                                                                                                     \
     case L:                                                                                                      \
-        if (mapped) launch_synthesis_fast16<L, true, double>(c, as_double_args(a), (unsigned)grid, s16, st);      \
+        if (mapped) launch_synthesis_fast16<L, true, R>(c, a, (unsigned)grid, s16, st);                          \
         else launch_synthesis_fast16<L, false, R>(c, a, (unsigned)grid, ola ? s16 : 16, st);                     \
         break;
             VOC_FOR_EACH_FAST16_LOG2M(X)
@@ -789,7 +785,7 @@ bool launch_synthesis_fast(voc_ctx *c, const voc::SynArgsT<R> &a, long long chan
     switch (c->log2m) {
 #define X(L)                                                                          \
     case L:                                                                           \
-        if (mapped) launch_synthesis_fast_nh<L, true, double, true>(c, as_double_args(a), (unsigned)grid, nh, st); \
+        if (mapped) launch_synthesis_fast_nh<L, true, R, true>(c, a, (unsigned)grid, nh, st);                     \
         else if (ola) launch_synthesis_fast_nh<L, true, R>(c, a, (unsigned)grid, nh, st);     \
         else hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, false, 8, R>), dim3((unsigned)grid), \
                                 dim3(voc::FastCfg<L>::T), voc::FastCfg<L>::template lds_bytes<R>(), st, params_of<R>(c), a); \
