@@ -288,3 +288,51 @@ def test_random_streams_single_precision(gpu_lib, seed):
         assert np.array_equal(y, y_ref.cpu().numpy())
         assert np.array_equal(st.phases()[1], s_ref.cpu().numpy())
     par.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_time_shards_against_the_unsharded_run(gpu_lib, seed):
+    """A signal cut by time over a random number of ranks (run one after the other here: halo frame, advances
+    summed in order, tails added) against the unsharded call: equal up to the re-association at the rank
+    boundaries, the last raw analysis phase bit for bit."""
+    import torch
+    from vocoder_amd import vocoder as V, conduit as Cd, timeshard as T
+    rng = np.random.default_rng(15000 + seed)
+    n = int(rng.choice([256, 1024, 2048, 4096, 8192, 16384]))
+    if seed % 3:
+        w, h = n, int(max(1, n // 16) * rng.choice([1, 2, 4, 8]))
+    else:
+        w = int(rng.integers(n // 2, n + 1))
+        h = int(rng.integers(max(1, w // 6), w + 1))
+    world = int(rng.integers(2, 6))
+    c = int(rng.integers(1, 4))
+    per_rank = -(-w // h) + 1                       # a rank's segment is at least as long as the overlap W - H
+    frames = int(rng.integers(world * per_rank, world * (per_rank + 6)))
+    length = w + h * (frames - 1) + int(rng.integers(0, h + 1))
+    par = V.VocoderParams(n, h, np.hanning(w + 2)[1:-1], lib=gpu_lib)
+    t = np.arange(length)
+    x = np.stack([0.5 * np.sin(2 * np.pi * (0.01 + 0.003 * i) * t + i) for i in range(c)]) + 1e-2 * rng.uniform(-1, 1, (c, length))
+    xt = torch.from_numpy(x).cuda()
+    plans = [T.plan(par, length, world, r) for r in range(world)]
+    ana = [T.analyse(par, sp, xt[:, sp.in_lo:sp.in_hi].contiguous()) for sp in plans]
+    totals = [T.local_advance(par, inc) for _, inc, _ in ana]
+    outs = [T.synthesise(par, sp, m, i, T.start_phase(totals, sp.rank)) for sp, (m, i, _) in zip(plans, ana)]
+    ys = []
+    for r, (sp, (y, _)) in enumerate(zip(plans, outs)):
+        if r > 0:
+            pv = plans[r - 1]
+            T.add_incoming_tail(y, outs[r - 1][0][:, pv.out_hi - pv.out_lo:].clone())
+        ys.append(y[:, :sp.out_hi - sp.out_lo])
+    y = torch.cat(ys, dim=1)
+    f = Cd.num_frames(par, length)
+    y_seq = torch.empty((c, Cd.ola_length(par, f, h)), dtype=torch.float64, device="cuda")
+    aph = torch.zeros((c, par.K), dtype=torch.float64, device="cuda")
+    sph = torch.zeros_like(aph)
+    Cd.process_dev(par, xt, y_seq, aph, sph)
+    torch.cuda.synchronize()
+    assert y.shape == y_seq.shape
+    assert (torch.linalg.norm(y - y_seq) / torch.linalg.norm(y_seq)).item() <= 1e-11
+    assert torch.equal(ana[-1][2], aph)
+    d = np.abs(outs[-1][1].cpu().numpy() - sph.cpu().numpy()) % (2 * np.pi)
+    assert np.minimum(d, 2 * np.pi - d).max() <= 1e-8
+    par.close()
