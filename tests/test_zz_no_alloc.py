@@ -130,3 +130,27 @@ def test_static_scratch_refuses_what_does_not_fit(gpu_lib):
     torch.cuda.synchronize()
     assert (y == 7.0).all()                         # nothing was touched
     par.close()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_static_scratch_on_random_shapes(gpu_lib, seed):
+    """Random frame lengths, windows, hops, channel counts and chunk sizes, one call after the other on the shared
+    array: the bits of voc_roundtrip_dev every time (lengths the entry point does not serve are refused, not run)."""
+    import torch
+    from vocoder_amd import vocoder as V, conduit as Cd
+    rng = np.random.default_rng(17000 + seed)
+    n = int(rng.choice([64, 256, 1024, 2048, 4096, 8192, 16384, 1000, 3000]))
+    if seed % 3:
+        w, h = n, max(1, n // int(rng.choice([2, 4, 8, 16])))
+    else:
+        w = int(rng.integers(max(3, n // 2), n + 1))
+        h = int(rng.integers(max(1, w // 6), w + 1))
+    c = int(rng.integers(1, 7))
+    length = w + h * int(rng.integers(0, 40)) + int(rng.integers(0, h + 1))
+    chunk = int(rng.choice([h, 1, 7, 1000]))
+    par = V.VocoderParams(n, h, np.hanning(w + 2)[1:-1], lib=gpu_lib)
+    x = torch.from_numpy(rng.standard_normal((c, length))).cuda()
+    (ys, as_, ss, ls), (yw, aw, sw, lw) = _both(par, x, chunk, seed=seed)
+    assert not torch.isnan(ys).any()
+    assert torch.equal(ys, yw) and torch.equal(as_, aw) and torch.equal(ss, sw) and torch.equal(ls, lw)
+    par.close()
