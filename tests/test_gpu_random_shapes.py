@@ -336,3 +336,43 @@ def test_random_time_shards_against_the_unsharded_run(gpu_lib, seed):
     d = np.abs(outs[-1][1].cpu().numpy() - sph.cpu().numpy()) % (2 * np.pi)
     assert np.minimum(d, 2 * np.pi - d).max() <= 1e-8
     par.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_long_lengths_stream_stage_and_fused_agree(gpu_lib, seed):
+    """Frame lengths between 4097 and 32768 that take the chirp-z transform through device memory: the fused
+    call, the stage-level chain and a stream pushed in pieces give the same bits, on rows at odd offsets too."""
+    import torch
+    from vocoder_amd import vocoder as V, conduit as Cd, stream as S
+    rng = np.random.default_rng(19000 + seed)
+    n = int(rng.integers(4097, 32769)) if seed % 4 else int(rng.choice([32768, 16385, 24576, 5000]))
+    w = n if seed % 2 else int(rng.integers(n // 2, n + 1))
+    h = int(rng.integers(max(1, w // 5), w + 1))
+    c = int(rng.integers(1, 3))
+    length = w + h * int(rng.integers(1, 6)) + int(rng.integers(0, h + 1))
+    chunk = int(rng.choice([h, 7, 1000]))
+    par = V.VocoderParams(n, h, np.hanning(w + 2)[1:-1], lib=gpu_lib)
+    x = rng.standard_normal((c, length))
+    a0, s0 = rng.uniform(-3, 3, (c, par.K)), rng.uniform(-3, 3, (c, par.K))
+    y_ref, left_ref, (a_ref, s_ref) = Cd.process_with(par, x, phases=(a0, s0), chunk=chunk)
+    cuts = np.concatenate([[0], np.sort(rng.integers(0, length + 1, 3)), [length]])
+    st = S.Stream(par, c, chunk, ana_phase=a0, syn_phase=s0)
+    y = np.concatenate([st.push(x[:, a:b]) for a, b in zip(cuts[:-1], cuts[1:])] + [st.flush()], axis=1)
+    assert np.array_equal(y, y_ref) and np.array_equal(st.leftover(), left_ref)
+    a, s = st.phases()
+    assert np.array_equal(a, a_ref) and np.array_equal(s, s_ref)
+    frames, left = Cd.frames_of_e(par, x)
+    aph, (mag, inc) = V.analysis_stage(par, a0, frames)
+    sph, out = V.synthesis_stage(par, s0, (mag * par.lib.dll.voc_volume_coeff(par.handle), inc))
+    assert np.array_equal(aph, a_ref) and np.array_equal(sph, s_ref)
+    assert np.array_equal(Cd.sum_frames_e(par, out, chunk), y_ref)
+    xb = torch.zeros(c * (length + 3) + 1, dtype=torch.float64, device="cuda")
+    xv = xb[1:].view(c, length + 3)[:, :length]
+    xv.copy_(torch.from_numpy(x))
+    yb = torch.zeros(c * (y_ref.shape[1] + 1) + 1, dtype=torch.float64, device="cuda")
+    yv = yb[1:].view(c, y_ref.shape[1] + 1)[:, :y_ref.shape[1]]
+    ad, sd = torch.from_numpy(a0).cuda(), torch.from_numpy(s0).cuda()
+    Cd.process_dev(par, xv, yv, ad, sd, length=length, chunk=chunk)
+    torch.cuda.synchronize()
+    assert np.array_equal(yv.cpu().numpy(), y_ref) and np.array_equal(sd.cpu().numpy(), s_ref)
+    par.close()
