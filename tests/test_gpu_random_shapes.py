@@ -376,3 +376,45 @@ def test_random_long_lengths_stream_stage_and_fused_agree(gpu_lib, seed):
     torch.cuda.synchronize()
     assert np.array_equal(yv.cpu().numpy(), y_ref) and np.array_equal(sd.cpu().numpy(), s_ref)
     par.close()
+
+
+def test_host_threads_share_one_context(gpu_lib):
+    """Several host threads on ONE context at once (the reference leaves this open, Vocoder.hs:98; vocoder-jack runs
+    its processing in a forked thread): calls serialise inside the library and every thread gets the bits it would
+    have got alone -- host-pointer round trips, single frames through analysisBlock / synthesisBlock, a stream
+    each, and a filter chain."""
+    import threading
+    from vocoder_amd import vocoder as V, conduit as Cd, stream as S, filter as Fl
+    n, h = 4096, 1024
+    par = V.VocoderParams(n, h, np.hanning(n + 2)[1:-1], lib=gpu_lib)
+    filt = (Fl.pitch_shift_interpolate(1.25) >> Fl.lowpass_butterworth(2.0, 3000.0)).bind(par, 48000.0 / n)
+    rng = np.random.default_rng(23)
+    jobs = [rng.standard_normal((2, n + h * int(rng.integers(3, 30)) + 5)) for _ in range(8)]
+
+    def work(x):
+        y, left, (a, s) = Cd.process_with(par, x)
+        ph, (mag, inc) = V.analysis_block(par, np.zeros(par.K), x[0, :n])
+        m2, i2 = filt.apply(mag[None, None], inc[None, None])
+        sp, fr = V.synthesis_block(par, np.zeros(par.K), (m2[0, 0], i2[0, 0]))
+        st = S.Stream(par, 2)
+        ys = np.concatenate([st.push(x[:, :777]), st.push(x[:, 777:]), st.flush()], axis=1)
+        return y, a, s, ph, fr, ys
+
+    alone = [work(x) for x in jobs]
+    got = [None] * len(jobs)
+    errs = []
+
+    def run(i):
+        try:
+            for _ in range(3):
+                got[i] = work(jobs[i])
+        except Exception as e:       # noqa: BLE001
+            errs.append(e)
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(len(jobs))]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errs, errs
+    for a, g in zip(alone, got):
+        assert all(np.array_equal(u, v) for u, v in zip(a, g))
+    par.close()
