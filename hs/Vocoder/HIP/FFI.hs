@@ -164,6 +164,11 @@ foreign import ccall unsafe "voc_roundtrip_workspace_bytes" c_voc_roundtrip_work
 foreign import ccall safe "voc_roundtrip_static_dev" c_voc_roundtrip_static_dev
     :: Ptr VocCtx -> Ptr Double -> Int64 -> Int64 -> Int64 -> Int64 -> Ptr Double -> Int64 -> Ptr Double -> Ptr Double
     -> Ptr Double -> Int64 -> Ptr () -> IO Int32
+-- | filter, mag, ph_inc, ldk, nframes, channels, phase_io, y, y_stride, y_len, stream: the chain, synthesisStage and
+--   sumFramesE in one call (a pitch shift and / or one gain table is applied by synthesis as it reads the rows)
+foreign import ccall safe "voc_synthesis_filtered_dev" c_voc_synthesis_filtered_dev
+    :: Ptr VocFilter -> Ptr Double -> Ptr Double -> Int64 -> Int64 -> Int64 -> Ptr Double -> Ptr Double -> Int64 -> Int64
+    -> Ptr () -> IO Int32
 -- | mag, ph_inc, ldk, nframes, channels, first_frame, first_channel, stream: the chain on a piece of a
 --   longer STFT (position-dependent filters number frames and channels from the given offsets)
 foreign import ccall safe "voc_filter_apply_at_dev" c_voc_filter_apply_at_dev

@@ -344,6 +344,16 @@ int32_t voc_filter_apply_dev(voc_filter *f, double *mag, double *ph_inc, int64_t
 int32_t voc_filter_apply_at_dev(voc_filter *f, double *mag, double *ph_inc, int64_t ldk, int64_t nframes,
                                 int64_t channels, int64_t first_frame, int64_t first_channel, void *stream);
 
+/* filter .| synthesisStage .| sumFramesE in one call (the middle of processWith, Conduit.hs:46-47, for a chain of
+ * per-frame filters): y as voc_filter_apply_dev followed by voc_synthesis_signal_dev would leave it, bit for bit.
+ * Where the chain is pitchShiftInterpolate and / or one linearAmplitudeFilter-based filter, in that order
+ * (Filter.hs:76-129), and the context runs the specialised double-precision kernels (N = 2048 ... 8192, W = N,
+ * hop a multiple of N/8), synthesis applies the chain to each row as it reads it and the pass over the STFT is
+ * saved; every other chain is applied first, in place.  mag / ph_inc are therefore left either untouched or
+ * filtered: a caller must not rely on their contents afterwards. */
+int32_t voc_synthesis_filtered_dev(voc_filter *f, double *mag, double *ph_inc, int64_t ldk, int64_t nframes, int64_t channels,
+                                   double *phase_io, double *y, int64_t y_stride, int64_t y_len, void *stream);
+
 /* ---- playSpeed (vocoder-conduit/src/Vocoder/Conduit/Filter.hs:122-136) --------------------------
  * playSpeed coeff replicates or drops STFT frames: after i input frames floor(i * coeff) frames
  * have been emitted, each emission repeating the newest input frame.  coeff = num / den exactly

@@ -418,3 +418,46 @@ def test_host_threads_share_one_context(gpu_lib):
     for a, g in zip(alone, got):
         assert all(np.array_equal(u, v) for u, v in zip(a, g))
     par.close()
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_chains_folded_into_synthesis(gpu_lib, monkeypatch, seed):
+    """voc_synthesis_filtered_dev: `pitch shift >> gain` chains are applied by synthesis to the rows it reads, every
+    other chain first and in place -- either way the bits of the filter pass followed by plain synthesis, on
+    contexts that have the specialised kernels and on those that do not, with few channels (tiles and the carry
+    pass on pitch-shifted increments) and many."""
+    import torch
+    from vocoder_amd import vocoder as V, conduit as Cd, filter as Fl
+    rng = np.random.default_rng(21000 + seed)
+    n = int(rng.choice([1024, 2048, 4096, 8192, 16384, 1000]))
+    if seed % 4:
+        w, h = n, max(1, n // int(rng.choice([2, 4, 8])))
+    else:
+        w = int(rng.integers(max(3, n // 2), n + 1))
+        h = int(rng.integers(max(1, w // 6), w + 1))
+    kind = seed % 5
+    if kind == 0:
+        descr = Fl.pitch_shift_interpolate(2.0) >> Fl.lowpass_brickwall(1000.0)
+    elif kind == 1:
+        descr = Fl.pitch_shift_interpolate(float(rng.uniform(0.4, 2.5)))
+    elif kind == 2:
+        descr = Fl.bandpass_butterworth(2.0, 300.0, 3400.0)
+    elif kind == 3:
+        descr = Fl.pitch_shift_interpolate(0.5) >> Fl.amplify(1.7)
+    else:
+        descr = Fl.lowpass_brickwall(4000.0) >> Fl.pitch_shift_interpolate(1.5) >> Fl.amplify(0.5)   # not foldable: applied first
+    c = int(rng.choice([1, 3, 40]))
+    frames = int(rng.integers(2, 40))
+    length = w + h * (frames - 1) + int(rng.integers(0, h + 1))
+    if seed % 2:
+        monkeypatch.setenv("VOC_SYN_SLOTS", "16")       # few slots: 40 channels leave a partial round, cut into tiles
+    par = V.VocoderParams(n, h, np.hanning(w + 2)[1:-1], lib=gpu_lib)
+    filt = descr.bind(par, 48000.0 / n)
+    x = torch.from_numpy(rng.standard_normal((c, length))).cuda()
+    s0 = torch.from_numpy(rng.uniform(-3, 3, (c, par.K))).cuda()
+    y, _, sph = Cd.process_filter_dev(par, filt, x, syn_phase=s0.clone())
+    monkeypatch.setenv("VOC_NO_FILTERED_SYNTHESIS", "1")
+    y_ref, _, sph_ref = Cd.process_filter_dev(par, filt, x, syn_phase=s0.clone())
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref) and torch.equal(sph, sph_ref)
+    par.close()

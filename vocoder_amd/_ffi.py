@@ -76,6 +76,7 @@ SIGNATURES = {
     "voc_filter_append": (_i32, [_vp, _i32, _vp, _i32]),
     "voc_filter_apply": (_i32, [_vp, _vp, _vp, _i64, _i64]),
     "voc_filter_apply_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "voc_synthesis_filtered_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _vp]),
     "voc_filter_apply_at_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp]),
     "voc_binary_frames_dev": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "voc_roundtrip_static_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),

@@ -10,6 +10,7 @@ triple, so a long stream can be fed segment by segment; `process` is the referen
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -188,6 +189,16 @@ def process_filter_dev(par: VocoderParams, filt, x, length: int | None = None, c
                   C.c_void_p(mag.data_ptr()), C.c_void_p(inc.data_ptr()), ldk, 1, st)
     mrows = irows = None
     fo = f
+    if (filt is not None and not f32 and f and x.is_cuda and len(filt.parts) == 1 and filt.parts[0][0] == "chain"
+            and not os.environ.get("VOC_NO_FILTERED_SYNTHESIS")):
+        # one chain of per-frame filters and nothing else: filter .| synthesis in one call (the library folds a
+        # `pitch shift >> gain` chain into synthesis' row loads and applies any other chain first)
+        n = ola_length(par, f, chunk)
+        y = torch.empty((c, n), dtype=dt, device=dev)
+        par.lib.check(par.lib.dll.voc_synthesis_filtered_dev(filt.parts[0][1]._h, C.c_void_p(mag.data_ptr()), C.c_void_p(inc.data_ptr()),
+                                                             ldk, f, c, C.c_void_p(sph.data_ptr()), C.c_void_p(y.data_ptr()),
+                                                             y.stride(0), n, st), par.handle)
+        return y, aph, sph
     if filt is not None:
         mag, mrows, inc, irows, fo = filt.apply_dev_lazy(mag, inc)
     n = ola_length(par, fo, chunk)

@@ -1067,8 +1067,39 @@ struct SynArgsT {
     // Null map: row f; F_mag / F_inc of 0: F.
     const long long *mag_rows, *inc_rows;
     long long F_mag, F_inc;
+    // Optional filter applied to a row as it is read (the double-precision overlap-add kernel of voc_kernels_fast.h
+    // built with FILT): pitchShiftInterpolate n (Filter.hs:118-129; 0: none) followed by one table of gains
+    // (linearAmplitudeFilter, Filter.hs:76-77; null: none) -- the chain `pitch >> gain` without a pass of its own
+    // over the STFT.  pitch_rcp: 1/n where that is exact (n a power of two), else 0 (the increments are divided).
+    double pitch_n, pitch_rcp;
+    const double *gain;
 };
 using SynArgs = SynArgsT<double>;
+
+// interpolate n v at bin k (Filter.hs:118-125) from the two entries it reads: position xp = n k, entries
+// floor(xp) and floor(xp) + 1, weights (1 - fr) and fr; 0 where xp >= K - 1.  The same operations in the same
+// order as the filter kernel's interpolate_at, so the bits are those of the filter pass.
+struct PitchTap {
+    int i;        // first entry (0 where the bin is out of range, so that loads stay inside the row)
+    double fr;
+    bool valid;
+};
+VOC_DEV PitchTap pitch_tap(double n, int k, int K)
+{
+    const double xp = n * (double)k;
+    PitchTap t;
+    t.valid = xp < (double)(K - 1);
+    const double fl = floor(xp);
+    t.i = t.valid ? (int)fl : 0;
+    t.fr = xp - (double)t.i;
+    return t;
+}
+VOC_DEV double pitch_mix(const PitchTap &t, double v0, double v1)
+{
+    const double lo = (1.0 - t.fr) * v0;
+    const double hi = t.fr * v1;
+    return t.valid ? lo + hi : 0.0;
+}
 
 // Row index of frame f of channel c in an array of `rows_per_channel` rows per channel, through an
 // optional map whose entries are clamped into the array (a bad entry reads a wrong row, never
@@ -1314,6 +1345,34 @@ __global__ void phase_carry_kernel(ParamsT<R> p, const R *__restrict__ inc, long
     for (; f < F && t < tiles; ++f) {
         const R d = src[f * ldk] * p.hop_d;
         ph = phase_step(ph, d);
+        if (f + 1 == next) {
+            carry[(c * tiles + t) * p.K + k] = ph;
+            ++t;
+            next += tile_len;
+        }
+    }
+}
+
+// The same chain on increments that pass through pitchShiftInterpolate n as they are read (the rows in memory are
+// the unfiltered ones; see SynArgsT::pitch_n): what the carry pass computes when the filter pass is folded into
+// synthesis.
+__global__ void phase_carry_pitch_kernel(ParamsT<double> p, const double *__restrict__ inc, long long ldk, long long F,
+                                         const double *__restrict__ phase_in, double *__restrict__ carry, int tile_len,
+                                         int tiles, int halo, long long channels, double pitch_n, double pitch_rcp)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= channels * p.K) return;
+    const long long c = g / p.K;
+    const int k = (int)(g % p.K);
+    const PitchTap tp = pitch_tap(pitch_n, k, p.K);
+    double ph = phase_in[c * p.K + k];
+    const double *src = inc + c * F * ldk + tp.i;
+    long long next = (long long)tile_len - halo;
+    int t = 1;
+    for (long long f = 0; f < F && t < tiles; ++f) {
+        const double v = pitch_mix(tp, src[f * ldk], src[f * ldk + 1]);
+        const double d = pitch_rcp != 0.0 ? v * pitch_rcp : v / pitch_n;
+        ph = phase_step(ph, d * p.hop_d);
         if (f + 1 == next) {
             carry[(c * tiles + t) * p.K + k] = ph;
             ++t;

@@ -928,9 +928,17 @@ constexpr int syn_lds_bytes()
 // the unmapped path 1 % when they are decided at run time).
 // ALIGNED = false: the output rows are not 16-byte aligned (an odd row stride or base): the emitted sample pairs
 // are stored as two 8-byte values each.  Same arithmetic: which build runs does not change a bit of the result.
-template <int LOG2M, bool OLA, int NHP, class R = double, bool MAPPED = false, bool ALIGNED = true>
+// FILT (the two-wave double-precision build only): the row passes through pitchShiftInterpolate and / or one table of
+// gains as it is read (SynArgsT::pitch_n, gain).  FILT = 2: each bin takes two neighbouring entries of the
+// unfiltered row, a frame ahead like the plain row, and mixes them where the plain build uses the entry itself --
+// the filter kernel's operations in its order, so the bits are those of a filter pass followed by the plain
+// build.  FILT = 1: a whole-number n (or no pitch shift): the weight of the second entry is zero, so only entry n k
+// is read (for finite rows the value of the filter pass, a zero's sign aside: the pass adds 0 times the second
+// entry).
+template <int LOG2M, bool OLA, int NHP, class R = double, bool MAPPED = false, bool ALIGNED = true, int FILT = 0>
 __global__ void __launch_bounds__(FastCfg<LOG2M>::T, (syn_fat<LOG2M, OLA, R>() ? 2 : VOC_FAST_WAVES)) synthesis_fast_kernel(ParamsT<R> p, SynArgsT<R> a)
 {
+    static_assert(FILT == 0 || (syn_fat<LOG2M, OLA, R>() && !MAPPED && VOC_SYN_PHASE_REGS != 0), "filtered rows: the two-wave overlap-add build");
     using C2 = cplx<R>;
     constexpr int M = FastCfg<LOG2M>::M, T = FastCfg<LOG2M>::T, N = 2 * M;
     constexpr int NP = 8;                       // sample pairs per thread
@@ -1002,6 +1010,23 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, (syn_fat<LOG2M, OLA, R>() ?
 
     // STFT row of frame f: (mag, ph_inc) of this thread's eight bins, plus DC / Nyquist for thread 0
     R mg[8], ic[8], mg0 = (R)0, mgm = (R)0, ic0 = (R)0, icm = (R)0;
+    // FILT: the second entry of every bin (the first is in the arrays above), and the gains of this frame's bins
+    constexpr int NF = FILT == 2 ? 8 : 1, NG = FILT != 0 ? 8 : 1;
+    R mg1[NF], ic1[NF], mg01 = (R)0, mgm1 = (R)0, ic01 = (R)0, icm1 = (R)0, gn[NG], gn0 = (R)1, gnm = (R)1;
+    const bool has_pitch = FILT != 0 && a.pitch_n != 0.0;
+    const int n_whole = FILT == 1 ? (int)a.pitch_n : 0;  // FILT = 1: the pitch factor as an integer (0: none)
+    // entry read for bin k with a whole-number factor, and whether the bin is in range (n k < K - 1)
+    auto whole_tap = [&](int k, bool &valid) -> int {
+        const int i = n_whole * k;
+        valid = n_whole == 0 || i < M;
+        return n_whole == 0 ? k : (valid ? i : 0);
+    };
+    // bin of row slot b (slots 2m, 2m + 1 are the pair m) of the thread whose opaque id is lt
+    auto slot_bin = [&](int b, int lt) -> int {
+        const int m = b >> 1;
+        const int pe = (m == 0 && lt == 0) ? M / 2 : lt + m * T;
+        return (b & 1) ? M - pe : pe;
+    };
     // Bins of pair slot m: pe = tid + m T (thread 0, slot 0: the self-paired bin M/2) and q = M - pe.  Their
     // byte offsets in a row are four per-thread values plus immediates: slot 0 has its own pair of
     // offsets, slots 1..3 sit at +-(m - 2) T elements around one offset each.
@@ -1009,6 +1034,50 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, (syn_fat<LOG2M, OLA, R>() ?
     // (formed from the frame's opaque copy of the thread id: hoisted, they become eight 64-bit row
     // pointers per thread that live across the whole loop)
     auto load_row = [&](long long f, int lt) {
+        if constexpr (FILT == 1) {
+            const R *mrow = a.mag + (c * a.F + f) * a.ldk, *irow = a.inc + (c * a.F + f) * a.ldk;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                bool valid;
+                const unsigned o0 = (unsigned)whole_tap(slot_bin(b, lt), valid) * SZ;
+                mg[b] = at_bytes(mrow, o0, 0);
+                ic[b] = at_bytes(irow, o0, 0);
+            }
+            if (tid == 0) {
+                bool valid;
+                const int im = whole_tap(M, valid);
+                mg0 = mrow[0];
+                ic0 = irow[0];
+                mgm = mrow[im];
+                icm = irow[im];
+            }
+            return;
+        }
+        if constexpr (FILT == 2) {
+            const R *mrow = a.mag + (c * a.F + f) * a.ldk, *irow = a.inc + (c * a.F + f) * a.ldk;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int k = slot_bin(b, lt);
+                const int i = has_pitch ? pitch_tap((double)a.pitch_n, k, M + 1).i : k;
+                const unsigned o0 = (unsigned)i * SZ, o1 = (unsigned)(i + (has_pitch ? 1 : 0)) * SZ;  // (no second entry without a pitch shift)
+                mg[b] = at_bytes(mrow, o0, 0);
+                mg1[b] = at_bytes(mrow, o1, 0);
+                ic[b] = at_bytes(irow, o0, 0);
+                ic1[b] = at_bytes(irow, o1, 0);
+            }
+            if (tid == 0) {
+                const int im = has_pitch ? pitch_tap((double)a.pitch_n, M, M + 1).i : M, im1 = im + (has_pitch ? 1 : 0);
+                mg0 = mrow[0];
+                mg01 = mrow[1];
+                ic0 = irow[0];
+                ic01 = irow[1];
+                mgm = mrow[im];
+                mgm1 = mrow[im1];
+                icm = irow[im];
+                icm1 = irow[im1];
+            }
+            return;
+        }
         const unsigned row_pe0 = (unsigned)(lt == 0 ? M / 2 : lt) * SZ, row_q0 = (unsigned)(M * SZ) - row_pe0;
         const unsigned row_pe2 = (unsigned)(lt + 2 * T) * SZ, row_q2 = (unsigned)(M * SZ) - row_pe2;
         const R *mrow = MAPPED ? mag_row_of(a, c, f) : a.mag + (c * a.F + f) * a.ldk;
@@ -1047,6 +1116,39 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, (syn_fat<LOG2M, OLA, R>() ?
         fast_tw_touch<LOG2M>(tw);
         wave_prio<VOC_PRIO_SYN_B, LOG2M>();
         if (!ROW_PF) load_row(f, lt);
+        if constexpr (FILT != 0) {
+            if (a.gain) {  // (requested here, used behind the first sine / cosine: live in the bin loop only)
+#pragma unroll
+                for (int b = 0; b < 8; ++b) gn[b] = a.gain[slot_bin(b, lt)];
+                if (tid == 0) {
+                    gn0 = a.gain[0];
+                    gnm = a.gain[M];
+                }
+            }
+        }
+        // the row as the filter pass would have left it: entries mixed (interpolate n), increments over n, gains
+        auto filtered = [&](int k, R v0, R v1, R w0, R w1, R g, R &mo, R &io) {
+            if constexpr (FILT == 1) {
+                bool valid;
+                (void)whole_tap(k, valid);
+                mo = v0;
+                io = w0;
+                if (n_whole != 0) {
+                    mo = valid ? v0 + (R)0 : (R)0;
+                    const R iv = valid ? w0 + (R)0 : (R)0;
+                    io = a.pitch_rcp != 0.0 ? iv * (R)a.pitch_rcp : iv / (R)a.pitch_n;
+                }
+            } else if (has_pitch) {
+                const PitchTap tp = pitch_tap((double)a.pitch_n, k, M + 1);
+                mo = pitch_mix(tp, v0, v1);
+                const R iv = pitch_mix(tp, w0, w1);
+                io = a.pitch_rcp != 0.0 ? iv * (R)a.pitch_rcp : iv / (R)a.pitch_n;
+            } else {
+                mo = v0;
+                io = w0;
+            }
+            if (a.gain) mo = mo * g;
+        };
         // m is a constant in every copy of the unrolled loop: the self-paired bin exists in the first
         // copy only, and the LDS addresses of the other pairs are one base each plus an immediate
         // (lds_sw is additive in multiples of 64, and T is one)
@@ -1074,6 +1176,12 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, (syn_fat<LOG2M, OLA, R>() ?
                 const C2 *col = twl + (lt & 15);
                 A = synthesize_bin_tab(p, mg[2 * m], ic[2 * m], phr[2 * m], col);
                 B = synthesize_bin_tab(p, mg[2 * m + 1], ic[2 * m + 1], phr[2 * m + 1], col);
+            } else if constexpr (FILT != 0) {
+                R ma, ia, mb, ib;
+                constexpr int s1 = FILT == 2 ? 1 : 0;  // (no second entries in the one-entry build)
+                filtered((int)pe, mg[2 * m], mg1[s1 * 2 * m], ic[2 * m], ic1[s1 * 2 * m], gn[2 * m], ma, ia);
+                filtered((int)q, mg[2 * m + 1], mg1[s1 * (2 * m + 1)], ic[2 * m + 1], ic1[s1 * (2 * m + 1)], gn[2 * m + 1], mb, ib);
+                synth_pair<LEAN>(p, ma, ia, phr[2 * m], mb, ib, phr[2 * m + 1], A, B);
             } else if constexpr (PHASE_REGS) {
                 synth_pair<LEAN>(p, mg[2 * m], ic[2 * m], phr[2 * m], mg[2 * m + 1], ic[2 * m + 1], phr[2 * m + 1], A, B);
             } else {
@@ -1101,6 +1209,15 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, (syn_fat<LOG2M, OLA, R>() ?
             if constexpr (!PHASE_REGS) {
                 ph0 = php[0];
                 phm = php[M];
+            }
+            if constexpr (FILT != 0) {
+                R m0, i0, mm, im;
+                filtered(0, mg0, mg01, ic0, ic01, gn0, m0, i0);
+                filtered(M, mgm, mgm1, icm, icm1, gnm, mm, im);
+                mg0 = m0;
+                ic0 = i0;
+                mgm = mm;
+                icm = im;
             }
             const C2 A = synthesize_bin(p, mg0, ic0, ph0);
             const C2 B = synthesize_bin(p, mgm, icm, phm);

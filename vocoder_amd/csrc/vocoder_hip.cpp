@@ -742,6 +742,24 @@ void launch_synthesis_fast_al(voc_ctx *c, const voc::SynArgsT<R> &a, unsigned gr
     }
 }
 
+// the build that filters the rows as it reads them (SynArgsT::pitch_n / gain): double precision, two waves per SIMD
+template <int L, bool ALIGNED, int FILT>
+void launch_synthesis_filtered_al(voc_ctx *c, const voc::SynArgsT<double> &a, unsigned grid, int nhp, hipStream_t st)
+{
+    if constexpr (voc::syn_fat<L, true, double>()) {
+        const dim3 g(grid), b(voc::FastCfg<L>::T);
+        const size_t lds = voc::syn_lds_bytes<L, true, double>();
+        switch (nhp) {
+        case 1: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, true, 1, double, false, ALIGNED, FILT>), g, b, lds, st, c->params, a); break;
+        case 2: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, true, 2, double, false, ALIGNED, FILT>), g, b, lds, st, c->params, a); break;
+        case 4: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, true, 4, double, false, ALIGNED, FILT>), g, b, lds, st, c->params, a); break;
+        default: hipLaunchKernelGGL((voc::synthesis_fast_kernel<L, true, 8, double, false, ALIGNED, FILT>), g, b, lds, st, c->params, a); break;
+        }
+    } else {
+        throw StatusFail{VOC_ERR_UNSUPPORTED};
+    }
+}
+
 template <int L, bool OLA, class R, bool MAPPED = false>
 void launch_synthesis_fast_nh(voc_ctx *c, const voc::SynArgsT<R> &a, unsigned grid, int nhp, hipStream_t st)
 {
@@ -750,6 +768,15 @@ void launch_synthesis_fast_nh(voc_ctx *c, const voc::SynArgsT<R> &a, unsigned gr
 }
 
 // Specialised synthesis kernel (polar input): frames out, or overlap-add out when fast_ola_nhp() != 0.
+// Whether a context's synthesis can filter its rows as it reads them (voc_synthesis_filtered_dev): the two-wave
+// double-precision overlap-add build of the eight-point kernel.
+inline bool synthesis_can_filter(const voc_ctx *c)
+{
+    voc::SynArgsT<double> none{};
+    return c->precision == VOC_PRECISION_F64 && VOC_SYN_FAT != 0 && fast_sizes(c) && c->log2m >= 10 && fast_ola_nhp(c, none) > 0 &&
+           fast16_hop_slots(c, true) == 0;
+}
+
 template <class R>
 bool launch_synthesis_fast(voc_ctx *c, const voc::SynArgsT<R> &a, long long channels, bool ola, hipStream_t st)
 {
@@ -782,6 +809,27 @@ bool launch_synthesis_fast(voc_ctx *c, const voc::SynArgsT<R> &a, long long chan
         return true;
     }
     if (!fast_sizes(c)) return false;
+    if constexpr (std::is_same<R, double>::value) {
+        if (a.pitch_n != 0.0 || a.gain) {  // (the caller has checked synthesis_can_filter)
+            if (!ola || mapped || !synthesis_can_filter(c)) throw StatusFail{VOC_ERR_UNSUPPORTED};
+            const bool al = rows_aligned16(a.out, a.out_stride);
+            // a whole-number factor (or none) reads one entry per bin: the lighter build
+            const bool one = a.pitch_n == 0.0 || (a.pitch_n >= 1.0 && a.pitch_n <= 64.0 && a.pitch_n == std::floor(a.pitch_n));
+            switch (c->log2m) {
+#define X(L)                                                                                          \
+    case L:                                                                                           \
+        if (one && al) launch_synthesis_filtered_al<L, true, 1>(c, a, (unsigned)grid, nh, st);        \
+        else if (one) launch_synthesis_filtered_al<L, false, 1>(c, a, (unsigned)grid, nh, st);        \
+        else if (al) launch_synthesis_filtered_al<L, true, 2>(c, a, (unsigned)grid, nh, st);          \
+        else launch_synthesis_filtered_al<L, false, 2>(c, a, (unsigned)grid, nh, st);                 \
+        break;
+                VOC_FOR_EACH_FAST_LOG2M(X)
+#undef X
+            }
+            HIPCHK(hipGetLastError());
+            return true;
+        }
+    }
     switch (c->log2m) {
 #define X(L)                                                                          \
     case L:                                                                           \
@@ -996,10 +1044,16 @@ template <class R = double>
 void synthesis_signal_dev(voc_ctx *c, const R *mag, const R *inc, long long ldk, long long F, long long C,
                           R *phase_io, R *y, long long y_stride, long long y_len, hipStream_t st,
                           const long long *mag_rows = nullptr, long long F_mag = 0, const long long *inc_rows = nullptr,
-                          long long F_inc = 0)
+                          long long F_inc = 0, double pitch_n = 0.0, const double *gain = nullptr)
 {
     if (C <= 0 || F <= 0) return;
     WsUse use(c, st);
+    const bool filtered = pitch_n != 0.0 || gain != nullptr;  // rows filtered as they are read (synthesis_can_filter contexts)
+    double pitch_rcp = 0.0;
+    if (pitch_n != 0.0) {
+        int e = 0;
+        if (std::frexp(pitch_n, &e) == 0.5) pitch_rcp = 1.0 / pitch_n;  // a power of two: the product is the quotient
+    }
     const bool fused = !c->bluestein && (lds_bytes<R>(c, true) <= kLdsLimit ||
                                          fast16_hop_slots(c, true) > 0);
     const int halo = fused ? (c->W + c->H - 1) / c->H - 1 : 0;
@@ -1017,10 +1071,20 @@ void synthesis_signal_dev(voc_ctx *c, const R *mag, const R *inc, long long ldk,
     if (tiles > 1 && C > unsplit) {
         const long long chains = (C - unsplit) * c->K;
         LaunchTimer timer(c, KIND_CARRY, st);
-        hipLaunchKernelGGL(voc::phase_carry_kernel<R>, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, params_of<R>(c),
-                           inc + (size_t)unsplit * (F_inc ? F_inc : F) * ldk, ldk, F, (const R *)(pin + unsplit * c->K), carry,
-                           tile_len, tiles, halo, C - unsplit, inc_rows, F_inc);
-        HIPCHK(hipGetLastError());
+        if constexpr (std::is_same<R, double>::value) {
+            if (pitch_n != 0.0) {  // the chain runs on the increments the filter would have written
+                hipLaunchKernelGGL(voc::phase_carry_pitch_kernel, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, c->params,
+                                   inc + (size_t)unsplit * F * ldk, ldk, F, (const double *)(pin + unsplit * c->K), carry, tile_len,
+                                   tiles, halo, C - unsplit, pitch_n, pitch_rcp);
+                HIPCHK(hipGetLastError());
+            }
+        }
+        if (pitch_n == 0.0) {
+            hipLaunchKernelGGL(voc::phase_carry_kernel<R>, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, params_of<R>(c),
+                               inc + (size_t)unsplit * (F_inc ? F_inc : F) * ldk, ldk, F, (const R *)(pin + unsplit * c->K), carry,
+                               tile_len, tiles, halo, C - unsplit, inc_rows, F_inc);
+            HIPCHK(hipGetLastError());
+        }
     }
     voc::SynArgsT<R> s{};
     s.mag = mag;
@@ -1041,6 +1105,10 @@ void synthesis_signal_dev(voc_ctx *c, const R *mag, const R *inc, long long ldk,
     s.inc_rows = inc_rows;
     s.F_mag = F_mag;
     s.F_inc = F_inc;
+    s.pitch_n = pitch_n;
+    s.pitch_rcp = pitch_rcp;
+    s.gain = gain;
+    if (filtered && !(fused && synthesis_can_filter(c))) throw StatusFail{VOC_ERR_UNSUPPORTED};
     if (fused) {
         if (!launch_synthesis_fast<R>(c, s, C, true, st)) launch_synthesis<voc::SYN_IN_POLAR, voc::SYN_OUT_OLA, R>(c, s, C, st);
     } else {
