@@ -25,7 +25,7 @@ Rank 0 prints one JSON line.  `roofline` is for the slower of the two kernels of
 duration measured with HIP events on the launch stream; `cpu_baseline` times the CPU oracle (a C
 restatement of the reference, one core) on a bounded sample of the same workload, `cpu_baseline_config1`
 on the reference's own CPU-runnable configuration in full; `parity` compares three streams of the
-metric run with the oracle after the timed region.
+metric run (two of a filtered run, with the oracle's filter chain) with the oracle after the timed region.
 
 The streams are a pure function of (seed, stream, sample index): Philox-4x32-10 keyed by the seed, the
 counter holding the stream and the sample index, so a host regenerates the device's samples bit for bit
@@ -173,6 +173,32 @@ def parity_check(par, win, x, y, streams=3, bar=1e-9):
         frames += int(r["nframes"])
     return {"ok": bool(worst <= bar), "rel_l2_max": worst, "bar": bar, "streams": streams, "frames": frames,
             "against": "CPU oracle (C restatement of the reference path) on the same samples, zero initial phases"}
+
+
+ORACLE_CHAINS = {"pitch2_lowpass1000": [("pitch_shift", 2.0), ("lowpass_brickwall", 1000.0)], "envelope32": [("envelope", 32)]}
+
+
+def parity_check_filtered(name, win, x, y, streams=2):
+    """The filtered configurations against the reference pipeline assembled from oracle pieces (analysis with volumeFix,
+    the filter chain of oracle/filters_oracle.c, synthesisStage, sumFramesE; Conduit.hs:46-47) on the first streams."""
+    import oracle
+    oracle.build()
+    worst, frames = 0.0, 0
+    k = N_FFT // 2 + 1
+    for s_ in range(streams):
+        rt = oracle.roundtrip(N_FFT, HOP, win, x[s_].double().cpu().numpy(), HOP, want_stft=True)
+        mag, inc = oracle.apply_filter(float(RATE) / N_FFT, ORACLE_CHAINS[name], rt["mag"], rt["ph_inc"])
+        _, fr = oracle.synthesis_stage(N_FFT, HOP, win, np.zeros(k), mag, inc)
+        ref = np.zeros(oracle.ola_length(mag.shape[0], N_FFT, HOP, HOP))
+        for j in range(mag.shape[0]):
+            ref[j * HOP:j * HOP + N_FFT] = ref[j * HOP:j * HOP + N_FFT] + fr[j]
+        got = y[s_].double().cpu().numpy()
+        if got.shape != ref.shape:
+            return {"ok": False, "error": f"stream {s_}: {got.shape} samples, oracle {ref.shape}"}
+        worst = max(worst, float(np.linalg.norm(got - ref) / np.linalg.norm(ref)))
+        frames += int(mag.shape[0])
+    return {"ok": bool(worst <= 1e-9), "rel_l2_max": worst, "bar": 1e-9, "streams": streams, "frames": frames,
+            "against": "CPU oracle pipeline with the same filter chain on the same samples, zero initial phases"}
 
 
 def cpu_baseline_all_cores(window, x_sample, cores):
@@ -324,7 +350,7 @@ def main():
             Cd.process_dev(par, x, y, aph, sph, workspace=ws)
         else:   # analysis .| volumeFix .| filter .| synthesis, the STFT in HBM between them (Conduit.hs:46-47); its
             # tensors come from torch's caching allocator: no device allocation after the warm-up steps
-            Cd.process_filter_dev(par, filt, x, ana_phase=aph, syn_phase=sph)
+            return Cd.process_filter_dev(par, filt, x, ana_phase=aph, syn_phase=sph)[0]
 
     def fence():
         torch.cuda.synchronize()
@@ -427,6 +453,11 @@ def main():
             # (single precision: 60 s of the metric signal stay within 1e-3 of the double-precision oracle, the
             #  float increments' rounding random-walking in the noise part; measured 2.8e-4)
             out["parity"] = parity_check(par, win, x, y, bar=1e-3 if f32 else 1e-9)
+        if world == 1 and filt is not None and not args.no_parity:
+            aph.zero_(); sph.zero_()
+            yf = step()
+            torch.cuda.synchronize()
+            out["parity"] = parity_check_filtered(args.filter, win, x, yf)
         if world == 1 and not args.no_cpu_baseline and filt is None:
             ncpu = min(args.cpu_streams, c)
             v, nfr, secs = cpu_baseline(win, x[:ncpu].double().cpu().numpy())
