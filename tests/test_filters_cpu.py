@@ -346,3 +346,28 @@ def test_binary_stream_operations_match_the_reference_definition(par, orc):
     ma, ia = V.add_frames(par, (m1, i1), (m2, i2))
     assert np.array_equal(mo.numpy(), ma, equal_nan=True) and np.array_equal(io.numpy(), ia, equal_nan=True)
     assert par.lib.dll.voc_binary_frames_dev(par.handle, 9, None, None, None, None, None, None, 0, None) == -1
+
+
+@pytest.mark.parametrize("n,hop,chain", [
+    (1024, 256, [("pitch_shift", 2.0), ("lowpass_brickwall", 1000.0)]),
+    (1024, 128, [("pitch_shift", 1.3)]),
+    (2048, 512, [("bandpass_butterworth", 2.0, 300.0, 3400.0)]),
+    (1024, 256, [("lowpass_brickwall", 4000.0), ("pitch_shift", 1.5)]),      # not foldable: applied first
+    (256, 64, [("pitch_shift", 2.0)]),                                        # no specialised kernel: applied first
+])
+def test_chain_folded_into_synthesis_equals_the_pass(emu_lib, monkeypatch, n, hop, chain):
+    """voc_synthesis_filtered_dev on the host build of the kernels (index logic): the bits of the filter pass
+    followed by plain synthesis, with few channels on few slots (tiles and the carry pass on mixed increments)."""
+    import torch
+    from vocoder_amd import vocoder as V, conduit as Cd
+    monkeypatch.setenv("VOC_SYN_SLOTS", "4")
+    par = V.VocoderParams(n, hop, np.hanning(n + 2)[1:-1], lib=emu_lib)
+    filt = _describe(chain).bind(par, 48000.0 / n)
+    rng = np.random.default_rng(n + hop)
+    x = torch.from_numpy(rng.standard_normal((3, n + hop * 21 + 5)))
+    s0 = torch.from_numpy(rng.uniform(-3, 3, (3, par.K)))
+    y, _, sph = Cd.process_filter_dev(par, filt, x, syn_phase=s0.clone())
+    monkeypatch.setenv("VOC_NO_FILTERED_SYNTHESIS", "1")
+    y_ref, _, sph_ref = Cd.process_filter_dev(par, filt, x, syn_phase=s0.clone())
+    assert torch.equal(y, y_ref) and torch.equal(sph, sph_ref)
+    par.close()

@@ -189,7 +189,7 @@ def process_filter_dev(par: VocoderParams, filt, x, length: int | None = None, c
                   C.c_void_p(mag.data_ptr()), C.c_void_p(inc.data_ptr()), ldk, 1, st)
     mrows = irows = None
     fo = f
-    if (filt is not None and not f32 and f and x.is_cuda and len(filt.parts) == 1 and filt.parts[0][0] == "chain"
+    if (filt is not None and not f32 and f and len(filt.parts) == 1 and filt.parts[0][0] == "chain"
             and not os.environ.get("VOC_NO_FILTERED_SYNTHESIS")):
         # one chain of per-frame filters and nothing else: filter .| synthesis in one call (the library folds a
         # `pitch shift >> gain` chain into synthesis' row loads and applies any other chain first)
