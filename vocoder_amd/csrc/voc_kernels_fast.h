@@ -902,6 +902,12 @@ constexpr bool syn_fat() { return VOC_SYN_FAT != 0 && LOG2M >= 10 && OLA && size
 // the two-wave build has room for from N = 4096 up (N = 4096: 2 x (2 x 32 KB + 8 KB) per CU).  Measured
 // (MI355X, metric shape, same box): four barriers per frame instead of eight leave the kernel where it was,
 // 27.3 against 27.1 ms -- it does not wait at barriers -- so this is off.
+// The two-entry rows of the FILT = 2 build of the synthesis kernel: requested a frame ahead like the plain row (64
+// registers across the transform: 21 spilled, 87 ms on the fourth configuration's shape with a factor of 1.5) or at
+// the top of their frame (245 registers, none spilled, 67 ms; the chain as a pass of its own: 94-97 ms).
+#ifndef VOC_FILT2_ROW_AHEAD
+#define VOC_FILT2_ROW_AHEAD 0
+#endif
 #ifndef VOC_SYN_PINGPONG
 #define VOC_SYN_PINGPONG 0
 #endif
@@ -1101,7 +1107,8 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, (syn_fat<LOG2M, OLA, R>() ?
         }
     };
 
-    if (ROW_PF) load_row(fs, opaque_int(tid));
+    constexpr bool ROW_AHEAD = VOC_FILT2_ROW_AHEAD != 0 || FILT != 2;  // (the two-entry rows of FILT = 2: a frame ahead or at use)
+    if (ROW_PF && ROW_AHEAD) load_row(fs, opaque_int(tid));
     C2 wres[NP];
     if constexpr (SFAT) {
 #pragma unroll
@@ -1115,7 +1122,7 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, (syn_fat<LOG2M, OLA, R>() ?
         const int lt = opaque_int(tid);  // keeps this frame's index arithmetic inside the loop
         fast_tw_touch<LOG2M>(tw);
         wave_prio<VOC_PRIO_SYN_B, LOG2M>();
-        if (!ROW_PF) load_row(f, lt);
+        if (!ROW_PF || !ROW_AHEAD) load_row(f, lt);
         if constexpr (FILT != 0) {
             if (a.gain) {  // (requested here, used behind the first sine / cosine: live in the bin loop only)
 #pragma unroll
@@ -1229,7 +1236,7 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, (syn_fat<LOG2M, OLA, R>() ?
             if constexpr (KEEP_IN) za[0] = z0;  // element 0; thread 0's slot 0 was bin M/2, which it reads back as element 4 T
             else lds[0] = z0;
         }
-        if (SFAT && f + 1 < f1) load_row(f + 1, lt);
+        if (SFAT && ROW_AHEAD && f + 1 < f1) load_row(f + 1, lt);
         wave_prio<VOC_PRIO_SYN_T, LOG2M>();
         VOC_STAMP(1);
         __syncthreads();
