@@ -39,12 +39,13 @@ struct FilterProg {
 VOC_DEV double interpolate_at(const double *v, int K, double n, int x)
 {
     const double xp = n * (double)x;
-    if (!(xp < (double)(K - 1))) return 0.0;  // i + 1 >= length v
-    const int i = (int)floor(xp);
+    const bool inside = xp < (double)(K - 1);  // else i + 1 >= length v: 0
+    // (no branch: out of range the two reads go to the start of the row and their mix is dropped)
+    const int i = inside ? (int)floor(xp) : 0;
     const double k = xp - (double)i;
     const double lo = (1.0 - k) * v[i];
     const double hi = k * v[i + 1];
-    return lo + hi;
+    return inside ? lo + hi : 0.0;
 }
 
 // convolution ker mag at bin k (Filter.hs:132-137): gmag is mag with h zeros on both sides
@@ -130,16 +131,16 @@ __global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p
         // row = channel * F + frame; the arrays hold rpc >= F rows per channel
         const long long prow = rpc == F ? row : (row / F) * rpc + row % F;
         S *mrow = mag + prow * ldk, *irow = inc + prow * ldk;
+        // (loads and table reads of slots past the last bin are clamped onto the last bin instead of predicated:
+        //  a predicated access is a block of its own with its own wait, and the values are never stored)
         double m[NE], ic[NE];
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
-            const int k = tid + T * j;
+            const int k = tid + T * j, kc = k < K ? k : K - 1;
             m[j] = 0.0;
             ic[j] = 0.0;
-            if (k < K) {
-                if (prog.load_mag) m[j] = (double)mrow[k];
-                if (prog.load_inc) ic[j] = (double)irow[k];
-            }
+            if (prog.load_mag) m[j] = (double)mrow[kc];
+            if (prog.load_inc) ic[j] = (double)irow[kc];
         }
         for (int o = 0; o < prog.n; ++o) {
             const FilterOp op = prog.op[o];
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
                     const int k = tid + T * j;
-                    if (k < K) m[j] = m[j] * op.table[k];
+                    m[j] = m[j] * op.table[k < K ? k : K - 1];
                 }
                 break;
             case FOP_PITCH:  // pitchShiftInterpolate (Filter.hs:128-129)
@@ -164,10 +165,8 @@ __global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
                     const int k = tid + T * j;
-                    if (k < K) {
-                        m[j] = interpolate_at(lm, K, op.a, k);
-                        if (!ONE) ic[j] = interpolate_at(li, K, op.a, k) / op.a;
-                    }
+                    m[j] = interpolate_at(lm, K, op.a, k);  // (0 without a read for every k past the row)
+                    if (!ONE) ic[j] = interpolate_at(li, K, op.a, k) / op.a;
                 }
                 __syncthreads();
                 if (ONE) {
@@ -207,7 +206,7 @@ __global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p
                 // pads the convolved array with len/2 zeros on either side, Filter.hs:132-137), so a tap is one
                 // LDS read and one multiply-add with the kernel value times 1/s -- no bounds test, no division.
                 // (Rows too long for two arrays, or kernels longer than a row, take the term-by-term form.)
-                if (!ONE && op.len <= K) {
+                if (!ONE && op.len <= K && T * NE + op.len <= 2 * ((K + 1) & ~1)) {
 #pragma unroll
                     for (int j = 0; j < NE; ++j) {
                         const int k = tid + T * j;
@@ -222,9 +221,11 @@ __global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p
 #pragma unroll 4
                     for (int i = 0; i < op.len; ++i) {
                         const double kr = op.table[i] * rs;
+                        // (no test per bin here: slots past the last bin read on inside the two arrays -- T NE + len
+                        //  <= 2 (K + 1) -- and their sums are never stored; with a test every tap of every bin becomes
+                        //  a predicated block of its own, one LDS read waited for at a time)
 #pragma unroll
-                        for (int j = 0; j < NE; ++j)
-                            if (tid + T * j < K) acc[j] = fma(kr, row[T * j + i], acc[j]);
+                        for (int j = 0; j < NE; ++j) acc[j] = fma(kr, row[T * j + i], acc[j]);
                     }
 #pragma unroll
                     for (int j = 0; j < NE; ++j) {
