@@ -1,7 +1,7 @@
 #!/bin/bash
 # Development aid: where the waves of tools/quick_bench.py (metric shape) wait -- LDS / vector-memory / instruction-fetch
 # latencies (accumulated in-flight level over issued count) and full-FIFO cycles, in separate passes.
-# usage: bash tools/pmc_latency.sh <tag>
+# usage: [BENCH=tools/quick_bench_f32.py] bash tools/pmc_latency.sh <tag>
 set -o pipefail
 tag=${1:-run}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
@@ -9,7 +9,7 @@ out=gpurun_out/pmcl_$tag
 rm -rf $out && mkdir -p $out
 pass() {
     local target=$1; shift
-    timeout -s KILL 200 rocprofv3 --pmc "$@" --output-format csv -d $out/pmc_run -- python3 tools/quick_bench.py ${CHANNELS:-1024} > /dev/null || return 1
+    timeout -s KILL 200 rocprofv3 --pmc "$@" --output-format csv -d $out/pmc_run -- python3 ${BENCH:-tools/quick_bench.py} ${CHANNELS:-1024} > /dev/null || return 1
     find $out/pmc_run -name "*counter_collection.csv" | head -1 | xargs -I{} python3 tools/pmc_summary.py {} >> $out/$target
     rm -rf $out/pmc_run
 }
