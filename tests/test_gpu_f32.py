@@ -41,6 +41,29 @@ def test_f32_roundtrip_on_device(gpu_lib, orc, n, w, hop):
     assert np.abs(sph).max() <= np.pi + 1e-6
 
 
+@pytest.mark.parametrize("ratio", [2, 4, 8, 16])
+@pytest.mark.parametrize("n", [1024, 2048, 4096, 8192, 16384])
+def test_f32_every_specialised_length_and_hop(gpu_lib, orc, n, ratio):
+    """The fused round trip on every frame length with a specialised kernel and every hop those kernels
+    distinguish (one build per length and hop ratio: sliding sample window, register overlap-add), each against
+    the double-precision oracle -- all channels, so that a build that goes wrong in one place cannot hide."""
+    from vocoder_amd import vocoder as V, conduit as Cd
+    hop = n // ratio
+    win = _hann(n)
+    p32 = V.VocoderParams(n, hop, win, lib=gpu_lib, precision="f32")
+    rng = np.random.default_rng(n + ratio)
+    c, length = 3, n + hop * 21 + 5
+    t = np.arange(length)
+    x = np.stack([0.5 * np.sin(2 * np.pi * 0.0071 * (i + 1) * t + i) for i in range(c)]) + 0.01 * rng.uniform(-1, 1, (c, length))
+    xf = x.astype(np.float32)
+    y, left, (aph, sph) = Cd.process_with(p32, xf)
+    assert np.isfinite(y).all() and np.abs(sph).max() <= np.pi + 1e-6
+    for i in range(c):
+        ref = orc.roundtrip(n, hop, win, xf[i].astype(np.float64), hop)
+        err = np.linalg.norm(y[i] - ref["y"]) / np.linalg.norm(ref["y"])
+        assert err <= TOL_F32_L2, (i, err)
+
+
 @pytest.mark.parametrize("n,w,hop", [(4096, 4096, 1024), (2048, 1500, 512), (256, 256, 64)])
 def test_f32_stage_signal_filter_and_stream_forms_on_device(gpu_lib, orc, n, w, hop):
     """The single-precision forms beyond the fused call: stages against the double-precision oracle to the variant's

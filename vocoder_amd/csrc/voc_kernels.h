@@ -85,6 +85,75 @@ template <class C> VOC_DEV C cmul_conj(C a, C b)  // a * conj(b)
 }
 template <class C> VOC_DEV C mul_mi(C a) { return mk2(a.y, -a.x); }  // a * (-i)
 template <class C> VOC_DEV C cconj(C a) { return mk2(a.x, -a.y); }
+// a * exp(-i pi/4) and a * exp(-3 i pi/4)
+template <class C> VOC_DEV C mul_w8(C a)
+{
+    using R = decltype(a.x);
+    return mk2((a.x + a.y) * (R)kSqrtHalf, (a.y - a.x) * (R)kSqrtHalf);
+}
+template <class C> VOC_DEV C mul_w8_3(C a)
+{
+    using R = decltype(a.x);
+    return mk2((a.y - a.x) * (R)kSqrtHalf, -((a.x + a.y) * (R)kSqrtHalf));
+}
+
+// two floats in one 64-bit register pair: the operand type of the packed instructions
+#ifdef VOC_EMU
+struct f32x2 { float x, y; };
+VOC_DEV f32x2 operator+(f32x2 a, f32x2 b) { return f32x2{a.x + b.x, a.y + b.y}; }
+VOC_DEV f32x2 operator-(f32x2 a, f32x2 b) { return f32x2{a.x - b.x, a.y - b.y}; }
+VOC_DEV f32x2 operator*(f32x2 a, f32x2 b) { return f32x2{a.x * b.x, a.y * b.y}; }
+VOC_DEV f32x2 operator-(f32x2 a) { return f32x2{-a.x, -a.y}; }
+VOC_DEV f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return f32x2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+#else
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+VOC_DEV f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
+VOC_DEV f32x2 pk2(float a, float b)
+{
+    f32x2 r;
+    r.x = a;
+    r.y = b;
+    return r;
+}
+VOC_DEV f32x2 splat2(float c) { return pk2(c, c); }
+
+// Single-precision complex arithmetic on packed registers: a complex number is one (re, im) register pair, a
+// complex sum one v_pk_add_f32, a product two instructions (the swaps and sign changes of i are operand
+// modifiers of the packed instructions).  Same roundings as the component-wise forms above.
+#ifndef VOC_F32_CPLX_PACKED
+#define VOC_F32_CPLX_PACKED 1
+#endif
+#if VOC_F32_CPLX_PACKED
+VOC_DEV f32x2 v2(float2 a) { return pk2(a.x, a.y); }
+VOC_DEV float2 c2(f32x2 a) { return make_float2(a.x, a.y); }
+// (a.y, a.x): an operand modifier of the consuming instruction.  A sign change of one component is not a modifier
+// the compiler forms, so those are products with (1, -1) / (-1, 1) fused into the sum they feed: x + (1, -1) y
+// rounds like x.x + y.x, x.y - y.y.
+#ifdef VOC_EMU
+VOC_DEV f32x2 swap2(f32x2 a) { return f32x2{a.y, a.x}; }
+#else
+VOC_DEV f32x2 swap2(f32x2 a) { return __builtin_shufflevector(a, a, 1, 0); }
+#endif
+VOC_DEV f32x2 sign_pm() { return pk2(1.0f, -1.0f); }
+VOC_DEV f32x2 sign_mp() { return pk2(-1.0f, 1.0f); }
+VOC_DEV float2 cadd(float2 a, float2 b) { return c2(v2(a) + v2(b)); }
+VOC_DEV float2 csub(float2 a, float2 b) { return c2(v2(a) - v2(b)); }
+VOC_DEV float2 cmul(float2 a, float2 b)
+{
+    // (a.x b.x - a.y b.y, a.x b.y + a.y b.x)
+    const f32x2 an = splat2(a.y) * sign_mp();
+    return c2(fma2(splat2(a.x), v2(b), an * swap2(v2(b))));
+}
+VOC_DEV float2 cmul_conj(float2 a, float2 b)
+{
+    // (a.x b.x + a.y b.y, a.y b.x - a.x b.y)
+    const f32x2 bn = splat2(b.y) * sign_pm();
+    return c2(fma2(v2(a), splat2(b.x), swap2(v2(a)) * bn));
+}
+VOC_DEV float2 mul_w8(float2 a) { return c2(fma2(swap2(v2(a)), sign_pm(), v2(a)) * splat2((float)kSqrtHalf)); }
+VOC_DEV float2 mul_w8_3(float2 a) { return c2(fma2(swap2(v2(a)), sign_pm(), -v2(a)) * splat2((float)kSqrtHalf)); }
+#endif
 VOC_DEV int lds_pad(int i) { return i + (i >> 3); }
 
 template <class C> VOC_DEV void bf2(C &a, C &b)
@@ -94,6 +163,21 @@ template <class C> VOC_DEV void bf2(C &a, C &b)
     b = csub(t, b);
 }
 
+// (a, b) <- (a - i b, a + i b): bf2 after b <- -i b
+template <class C> VOC_DEV void bf2_mi(C &a, C &b)
+{
+    b = mul_mi(b);
+    bf2(a, b);
+}
+#if VOC_F32_CPLX_PACKED
+VOC_DEV void bf2_mi(float2 &a, float2 &b)
+{
+    const f32x2 t = v2(a), u = swap2(v2(b));
+    a = c2(fma2(u, sign_pm(), t));
+    b = c2(fma2(u, sign_mp(), t));
+}
+#endif
+
 // Forward DFT of RAD points in place, natural order in and out.
 template <class C> VOC_DEV void dft_n(C (&v)[2]) { bf2(v[0], v[1]); }
 
@@ -101,9 +185,8 @@ template <class C> VOC_DEV void dft_n(C (&v)[4])
 {
     bf2(v[0], v[2]);
     bf2(v[1], v[3]);
-    v[3] = mul_mi(v[3]);
     bf2(v[0], v[1]);
-    bf2(v[2], v[3]);
+    bf2_mi(v[2], v[3]);
     C t = v[1];  // bit-reversed -> natural
     v[1] = v[2];
     v[2] = t;
@@ -111,26 +194,21 @@ template <class C> VOC_DEV void dft_n(C (&v)[4])
 
 template <class C> VOC_DEV void dft_n(C (&v)[8])
 {
-    using R = decltype(v[0].x);
-    const R kh = (R)kSqrtHalf;
     bf2(v[0], v[4]);
     bf2(v[1], v[5]);
     bf2(v[2], v[6]);
     bf2(v[3], v[7]);
     // twiddles W8^1, W8^2, W8^3 on the lower half
-    v[5] = mk2((v[5].x + v[5].y) * kh, (v[5].y - v[5].x) * kh);
-    v[6] = mul_mi(v[6]);
-    v[7] = mk2((v[7].y - v[7].x) * kh, -((v[7].x + v[7].y) * kh));
+    v[5] = mul_w8(v[5]);
+    v[7] = mul_w8_3(v[7]);
     bf2(v[0], v[2]);
     bf2(v[1], v[3]);
-    v[3] = mul_mi(v[3]);
-    bf2(v[4], v[6]);
+    bf2_mi(v[4], v[6]);
     bf2(v[5], v[7]);
-    v[7] = mul_mi(v[7]);
     bf2(v[0], v[1]);
-    bf2(v[2], v[3]);
+    bf2_mi(v[2], v[3]);
     bf2(v[4], v[5]);
-    bf2(v[6], v[7]);
+    bf2_mi(v[6], v[7]);
     // registers now hold y0 y4 y2 y6 y1 y5 y3 y7
     C t;
     t = v[1]; v[1] = v[4]; v[4] = t;
@@ -680,25 +758,6 @@ VOC_DEV float phase_inc(const ParamsT<float> &p, int k, float ph_diff)
 #ifndef VOC_F32_PACKED
 #define VOC_F32_PACKED 1
 #endif
-#ifdef VOC_EMU
-struct f32x2 { float x, y; };
-VOC_DEV f32x2 operator+(f32x2 a, f32x2 b) { return f32x2{a.x + b.x, a.y + b.y}; }
-VOC_DEV f32x2 operator-(f32x2 a, f32x2 b) { return f32x2{a.x - b.x, a.y - b.y}; }
-VOC_DEV f32x2 operator*(f32x2 a, f32x2 b) { return f32x2{a.x * b.x, a.y * b.y}; }
-VOC_DEV f32x2 operator-(f32x2 a) { return f32x2{-a.x, -a.y}; }
-VOC_DEV f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return f32x2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
-#else
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-VOC_DEV f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-#endif
-VOC_DEV f32x2 pk2(float a, float b)
-{
-    f32x2 r;
-    r.x = a;
-    r.y = b;
-    return r;
-}
-VOC_DEV f32x2 splat2(float c) { return pk2(c, c); }
 // a kernel argument used as one lane-uniform float (kept in its scalar register: without this the compiler
 // gathers neighbouring arguments into vectors through the stack)
 VOC_DEV float uniform_f(float v)

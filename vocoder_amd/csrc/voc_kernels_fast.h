@@ -182,6 +182,31 @@ VOC_DEV void merge_pair_polar(R mag, R c, R s, C2 B, C2 tw, C2 &Za, C2 &Zb)
     Zb = mk2(fma((R)-2, S.y, Za.x), fma((R)2, S.x, -Za.y));
 }
 
+#if VOC_F32_CPLX_PACKED
+// split_pair_x2 and merge_pair on packed registers (float): E = P + conj Q, O = -i P + swap Q and the like are one
+// instruction each; same roundings
+VOC_DEV void split_pair_x2(float2 P, float2 Q, float2 tw, float2 &Xa, float2 &Xb)
+{
+    const f32x2 E = fma2(v2(Q), sign_pm(), v2(P));
+    const f32x2 O = fma2(swap2(v2(P)), sign_pm(), swap2(v2(Q)));
+    const f32x2 A = fma2(splat2(tw.x), O, fma2(splat2(tw.y) * sign_mp(), swap2(O), E));
+    const f32x2 Bc = fma2(splat2(2.0f), E, -A);   // conj of 2 X[q]
+    Xa = c2(A);
+    Xb = make_float2(Bc.x, -Bc.y);
+}
+VOC_DEV void merge_pair(float2 A, float2 B, float2 tw, float2 &Za, float2 &Zb)
+{
+    const f32x2 S = fma2(v2(B), sign_pm(), v2(A));
+    const f32x2 D = fma2(v2(B), sign_mp(), v2(A));
+    // Za = (S.y, S.x) + D.x (tw.x, tw.y) + D.y (tw.y, -tw.x)
+    const f32x2 a = fma2(splat2(D.x), v2(tw), fma2(splat2(D.y) * sign_pm(), swap2(v2(tw)), swap2(S)));
+    // Zb = (a.x - 2 S.y, 2 S.x - a.y)
+    const f32x2 b = fma2(splat2(2.0f), swap2(S), -a) * sign_mp();
+    Za = c2(a);
+    Zb = c2(b);
+}
+#endif
+
 // Where complex element i of the transform lives in LDS: i with its low three bits XORed by the next
 // three.  A pass reads 16-byte elements that are contiguous over the lanes and writes elements that are
 // 8 (or 64, 512) apart over the lanes; the LDS serves a 16-byte read in groups of 16 lanes over 64
@@ -211,6 +236,18 @@ VOC_DEV void opaque(C2 &a)
     (void)a;
 #endif
 }
+
+#if VOC_F32_CPLX_PACKED && !defined(VOC_EMU)
+// (a float pair is marked as one 64-bit register pair: marked component by component, the compiler at hand took the
+//  second component of a loop-carried pair for the undefined half of a splat operand and dropped its initial copy --
+//  visible in the assembly as "kill: def $vgprN killed $vgprM" -- in the one-wave analysis kernels)
+VOC_DEV void opaque(float2 &a)
+{
+    f32x2 t = v2(a);
+    asm volatile("" : "+v"(t));
+    a = c2(t);
+}
+#endif
 
 // Same for an integer: index arithmetic derived from an opaque copy of the thread id is redone
 // every frame (a few integer instructions) instead of being hoisted as dozens of loop-invariant
@@ -281,18 +318,27 @@ VOC_DEV void bf2_tw(C2 t, C2 u, C2 w, C2 &a, C2 &b)
     b = mk2(fma((R)2, t.x, -a.x), fma((R)2, t.y, -a.y));
 }
 
+#if VOC_F32_CPLX_PACKED
+VOC_DEV float2 csqr(float2 a) { return cmul(a, a); }
+VOC_DEV void bf2_tw(float2 t, float2 u, float2 w, float2 &a, float2 &b)
+{
+    const f32x2 wn = splat2(w.y) * sign_mp();
+    const f32x2 A = fma2(splat2(w.x), v2(u), fma2(wn, swap2(v2(u)), v2(t)));
+    a = c2(A);
+    b = c2(fma2(splat2(2.0f), v2(t), -A));
+}
+#endif
+
 // the radix-8 butterfly after its first stage (v[j] +- v[j + 4] done): as dft_n for eight points, with the
 // factor sqrt(1/2) of the eighth-turn twiddles fused into the butterfly that follows them
 template <class C2>
 VOC_DEV void dft8_rest(C2 (&v)[8])
 {
     using R = decltype(v[0].x);
-    const R kh = (R)kSqrtHalf;
-    v[6] = mul_mi(v[6]);
+    [[maybe_unused]] const R kh = (R)kSqrtHalf;
     bf2(v[0], v[2]);
     bf2(v[1], v[3]);
-    v[3] = mul_mi(v[3]);
-    bf2(v[4], v[6]);
+    bf2_mi(v[4], v[6]);
 #if VOC_FMA_MORE
     {   // v5 <- W8 v5 = kh p5, v7 <- W8^3 v7 = kh p7, then (v5, v7) <- (v5 + v7, v5 - v7)
         const C2 p5 = mk2(v[5].x + v[5].y, v[5].y - v[5].x);
@@ -302,15 +348,14 @@ VOC_DEV void dft8_rest(C2 (&v)[8])
         v[7] = mk2(fma(kh, p5.x, -t7.x), fma(kh, p5.y, -t7.y));
     }
 #else
-    v[5] = mk2((v[5].x + v[5].y) * kh, (v[5].y - v[5].x) * kh);
-    v[7] = mk2((v[7].y - v[7].x) * kh, -((v[7].x + v[7].y) * kh));
+    v[5] = mul_w8(v[5]);
+    v[7] = mul_w8_3(v[7]);
     bf2(v[5], v[7]);
 #endif
-    v[7] = mul_mi(v[7]);
     bf2(v[0], v[1]);
-    bf2(v[2], v[3]);
+    bf2_mi(v[2], v[3]);
     bf2(v[4], v[5]);
-    bf2(v[6], v[7]);
+    bf2_mi(v[6], v[7]);
     C2 t;
     t = v[1]; v[1] = v[4]; v[4] = t;
     t = v[3]; v[3] = v[6]; v[6] = t;
@@ -349,9 +394,9 @@ VOC_DEV void dft4_tw(C2 (&v)[4], C2 w1)
     v[2] = b;
     bf2_tw(cmul(v[1], w1), v[3], cmul(w2, w1), a, b);
     v[1] = a;
-    v[3] = mul_mi(b);
+    v[3] = b;
     bf2(v[0], v[1]);
-    bf2(v[2], v[3]);
+    bf2_mi(v[2], v[3]);
     const C2 t = v[1];
     v[1] = v[2];
     v[2] = t;

@@ -93,7 +93,7 @@ VOC_DEV void dft16(C2 (&v)[16], C2 w1)
         const C2 w2 = csqr(w1);
         dft8_tw(e, w2);
         dft8_tw(o, w2);
-        const C2 g1 = cmul(w1, mk2(c1, -s1)), g2 = mk2((w1.x + w1.y) * kh, (w1.y - w1.x) * kh), g3 = cmul(w1, mk2(s1, -c1));
+        const C2 g1 = cmul(w1, mk2(c1, -s1)), g2 = mul_w8(w1), g3 = cmul(w1, mk2(s1, -c1));
         const C2 g[8] = {w1, g1, g2, g3, mul_mi(w1), mul_mi(g1), mul_mi(g2), mul_mi(g3)};
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -112,9 +112,9 @@ VOC_DEV void dft16(C2 (&v)[16], C2 w1)
                 a = cadd(e[k], o[k]);
                 b = csub(e[k], o[k]);
             } else if (k == 4) {
-                const C2 u = mul_mi(o[k]);
-                a = cadd(e[k], u);
-                b = csub(e[k], u);
+                a = e[k];
+                b = o[k];
+                bf2_mi(a, b);
             } else {
                 bf2_tw(e[k], o[k], g[k], a, b);
             }
