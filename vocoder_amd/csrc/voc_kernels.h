@@ -758,6 +758,12 @@ VOC_DEV float phase_inc(const ParamsT<float> &p, int k, float ph_diff)
 #ifndef VOC_F32_PACKED
 #define VOC_F32_PACKED 1
 #endif
+#ifndef VOC_F32_HW_SINCOS
+#define VOC_F32_HW_SINCOS 1
+#endif
+#ifndef VOC_F32_ATAN_REFINE
+#define VOC_F32_ATAN_REFINE 1
+#endif
 // a kernel argument used as one lane-uniform float (kept in its scalar register: without this the compiler
 // gathers neighbouring arguments into vectors through the stack)
 VOC_DEV float uniform_f(float v)
@@ -770,34 +776,48 @@ VOC_DEV float uniform_f(float v)
 VOC_DEV unsigned f32_bits(float v) { return __builtin_bit_cast(unsigned, v); }
 VOC_DEV float f32_of(unsigned b) { return __builtin_bit_cast(float, b); }
 
-// frameFromComplex of the bins xa + i ya and xb + i yb.  The pair (max, min) of (|x|, |y|) is scaled by the power
-// of two that brings the larger into [1, 2) -- a product with a float assembled from the exponent bits, and the
-// magnitude is scaled back by the float with just those bits -- so squares neither overflow nor underflow;
-// atan(min / max) with the fold at tan(pi/8) before the division; the octant is undone by two +-1 factors.
-// A zero bin gives magnitude 0 and phase 0 (pi for x = -0); denormal components count as zero.
-VOC_DEV void hs_polar_pair(float xa, float ya, float xb, float yb, float &ma, float &pa, float &mb, float &pb)
+// frameFromComplex of the bins xa + i ya and xb + i yb, the magnitudes times `scale`.  atan(min / max) of
+// (|x|, |y|) with the fold at tan(pi/8) before the division; the octant is undone by two +-1 factors.
+// A zero bin gives magnitude 0 and phase 0 (pi for x = -0).  VOC_F32_POLAR_SCALED: the pair (max, min) is first
+// scaled by the power of two that brings the larger into [1, 2) -- a product with a float assembled from the
+// exponent bits, and the magnitude is scaled back by the float with just those bits -- so that the squares neither
+// overflow nor underflow (seven instructions per pair); without it a bin must stay within 1e-19 .. 1e19 for its
+// magnitude to come out, which single-precision audio does by twelve orders of magnitude on either side.
+#ifndef VOC_F32_POLAR_SCALED
+#define VOC_F32_POLAR_SCALED 0
+#endif
+VOC_DEV void hs_polar_pair(float xa, float ya, float xb, float yb, float scale, float &ma, float &pa, float &mb, float &pb)
 {
     const f32x2 mx = pk2(fmaxf(fabsf(xa), fabsf(ya)), fmaxf(fabsf(xb), fabsf(yb)));
     const f32x2 mn = pk2(fminf(fabsf(xa), fabsf(ya)), fminf(fabsf(xb), fabsf(yb)));
+#if VOC_F32_POLAR_SCALED
     const unsigned ea = f32_bits(mx.x) & 0x7f800000u, eb = f32_bits(mx.y) & 0x7f800000u;
     const f32x2 down = pk2(f32_of(0x7f000000u - ea), f32_of(0x7f000000u - eb));  // 2^-e (2^127 for a zero bin: 0 stays 0)
     const f32x2 up = pk2(f32_of(ea), f32_of(eb));                                  // 2^e
     const f32x2 MX = mx * down, MN = mn * down;                                    // MX in [1, 2) or 0
+#else
+    const f32x2 MX = mx, MN = mn;
+#endif
     const f32x2 ss = fma2(MN, MN, MX * MX);
 #ifdef VOC_EMU
     const f32x2 r = pk2(sqrtf(ss.x), sqrtf(ss.y));
 #else
     const f32x2 r = pk2(__builtin_amdgcn_sqrtf(ss.x), __builtin_amdgcn_sqrtf(ss.y));
 #endif
-    const f32x2 mag = r * up;
+#if VOC_F32_POLAR_SCALED
+    const f32x2 mag = (r * up) * splat2(scale);
+#else
+    const f32x2 mag = r * splat2(scale);
+#endif
     const f32x2 lim = MX * splat2(0.41421356f);
     const f32x2 f = pk2(MN.x > lim.x ? 1.0f : 0.0f, MN.y > lim.y ? 1.0f : 0.0f);
     const f32x2 num = fma2(-f, MX, MN);
     const f32x2 d0 = fma2(f, MN, MX);
-    const f32x2 den = pk2(fmaxf(d0.x, 1e-30f), fmaxf(d0.y, 1e-30f));
+    constexpr float tiny = VOC_F32_POLAR_SCALED ? 1e-30f : 1e-37f;   // (a zero bin: 0 / tiny = 0)
+    const f32x2 den = pk2(fmaxf(d0.x, tiny), fmaxf(d0.y, tiny));
     const f32x2 rc = pk2(approx_rcp(den.x), approx_rcp(den.y));
     f32x2 q = num * rc;
-    q = fma2(fma2(-den, q, num), rc, q);
+    if (VOC_F32_ATAN_REFINE) q = fma2(fma2(-den, q, num), rc, q);
     const f32x2 z = q * q;
     f32x2 p = splat2(-0.06466829776763916f);
     p = fma2(p, z, splat2(0.10748856514692307f));
@@ -817,12 +837,11 @@ VOC_DEV void hs_polar_pair(float xa, float ya, float xb, float yb, float &ma, fl
     pb = copysignf(t.y, yb);
 }
 
-// phase_inc_pow2 of the bins ka and kb
-VOC_DEV void phase_inc_pow2_pair(const ParamsT<float> &p, int ka, int kb, float da, float db, float &ia, float &ib)
+// phase_inc_pow2 of two bins whose numbers are given as floats (kf) together with kmhi = (k mod N/H) om1_hi
+VOC_DEV void phase_inc_pow2_pair_kf(const ParamsT<float> &p, f32x2 kf, f32x2 kmhi, float da, float db, float &ia, float &ib)
 {
-    const f32x2 kf = pk2((float)ka, (float)kb), km = pk2((float)(ka & p.turn_mask), (float)(kb & p.turn_mask));
     const f32x2 hi = splat2(uniform_f(p.om1_hi));
-    const f32x2 x = pk2(da, db) - km * hi;                                         // ph_diff - (k mod N/H) omega1: product, then difference, as phase_inc_pow2
+    const f32x2 x = pk2(da, db) - kmhi;                                            // ph_diff - (k mod N/H) omega1: product, then difference, as phase_inc_pow2
     const f32x2 u = (x + splat2(kPiF)) * splat2(kInvTwoPiF);
     const f32x2 n = pk2(floorf(u.x), floorf(u.y));
     const f32x2 w = fma2(-n, splat2(kTwoPiLoF), fma2(-n, splat2(kTwoPiHiF), x));   // wrap_floor_f
@@ -833,6 +852,29 @@ VOC_DEV void phase_inc_pow2_pair(const ParamsT<float> &p, int ka, int kb, float 
     ib = r.y;
 }
 
+// phase_inc_pow2 of the bins ka and kb
+VOC_DEV void phase_inc_pow2_pair(const ParamsT<float> &p, int ka, int kb, float da, float db, float &ia, float &ib)
+{
+    const f32x2 kf = pk2((float)ka, (float)kb), km = pk2((float)(ka & p.turn_mask), (float)(kb & p.turn_mask));
+    phase_inc_pow2_pair_kf(p, kf, km * splat2(uniform_f(p.om1_hi)), da, db, ia, ib);
+}
+
+// The bin pairs of a thread of the specialised kernels are (t + m T, M - t - m T), T a multiple of N/H: as floats
+// (exact) the two numbers are fa and M - fa with fa = t + m T, and k mod N/H is the same for every m.  What does not
+// depend on m is formed once per frame; a pair then costs two instructions where the conversions of its two bin
+// numbers and of their remainders cost eight.  Double precision has no use for it (its phase_inc_pow2 takes integers).
+template <class R> struct PairBinsT {
+    VOC_DEV void frame(const ParamsT<R> &, int) {}
+};
+template <> struct PairBinsT<float> {
+    float ft;
+    f32x2 kmhi;
+    VOC_DEV void frame(const ParamsT<float> &p, int lt)
+    {
+        ft = (float)lt;
+        kmhi = pk2((float)(lt & p.turn_mask), (float)((0 - lt) & p.turn_mask)) * splat2(uniform_f(p.om1_hi));
+    }
+};
 // synthesisStep of two bins: phase steps (phase_step for float), then mkPolar; LEAN is accepted and ignored
 VOC_DEV void synthesize_pair(const ParamsT<float> &p, float mga, float ica, float &pha, float mgb, float icb, float &phb,
                              float2 &A, float2 &B)
@@ -846,6 +888,18 @@ VOC_DEV void synthesize_pair(const ParamsT<float> &p, float mga, float ica, floa
     const f32x2 ph = fma2(-n2, splat2(kTwoPiLoF), fma2(-n2, splat2(kTwoPiHiF), s));   // wrap_floor_f
     pha = ph.x;
     phb = ph.y;
+#if VOC_F32_HW_SINCOS
+    // sine and cosine from the hardware (v_sin_f32 / v_cos_f32: argument in turns, within 1.3e-7 of the exact values
+    // over [-0.5, 0.5], measured; two issue slots each, against 30 for range reduction, two polynomials and quadrants)
+    const f32x2 tu = ph * splat2(kInvTwoPiF);
+#ifdef VOC_EMU
+    const f32x2 sg = pk2(sinf(6.28318530717958647692f * tu.x), sinf(6.28318530717958647692f * tu.y));
+    const f32x2 cg = pk2(cosf(6.28318530717958647692f * tu.x), cosf(6.28318530717958647692f * tu.y));
+#else
+    const f32x2 sg = pk2(__builtin_amdgcn_sinf(tu.x), __builtin_amdgcn_sinf(tu.y));
+    const f32x2 cg = pk2(__builtin_amdgcn_cosf(tu.x), __builtin_amdgcn_cosf(tu.y));
+#endif
+#else
     // fast_sincos for float, both bins
     const f32x2 v = ph * splat2(0.636619772f);
     const f32x2 n = pk2(rintf(v.x), rintf(v.y));
@@ -867,6 +921,7 @@ VOC_DEV void synthesize_pair(const ParamsT<float> &p, float mga, float ica, floa
     const f32x2 sg = pk2(f32_of(f32_bits(s1a) ^ (((unsigned)qa << 30) & 0x80000000u)), f32_of(f32_bits(s1b) ^ (((unsigned)qb << 30) & 0x80000000u)));
     const f32x2 cg = pk2(f32_of(f32_bits(c1a) ^ ((((unsigned)qa + 1u) << 30) & 0x80000000u)),
                          f32_of(f32_bits(c1b) ^ ((((unsigned)qb + 1u) << 30) & 0x80000000u)));
+#endif
     const f32x2 mg = pk2(mga, mgb);
     const f32x2 re = mg * cg, im = mg * sg;
     A = make_float2(re.x, im.x);
@@ -907,20 +962,43 @@ VOC_DEV cplx<R> synthesize_bin(const ParamsT<R> &p, R mag, R inc, R &ph)
 
 // Two bins at a time: the double-precision kernels (and float builds without VOC_F32_PACKED) take the one-bin
 // functions twice, float takes the packed forms above.
+// (the magnitudes come back multiplied by `scale`)
 template <bool LEAN>
-VOC_DEV void polar_pair(double2 Xa, double2 Xb, double &ma, double &pa, double &mb, double &pb)
+VOC_DEV void polar_pair(double2 Xa, double2 Xb, double scale, double &ma, double &pa, double &mb, double &pb)
 {
     hs_polar<LEAN>(Xa.x, Xa.y, ma, pa);
     hs_polar<LEAN>(Xb.x, Xb.y, mb, pb);
+    ma *= scale;
+    mb *= scale;
 }
 template <bool LEAN>
-VOC_DEV void polar_pair(float2 Xa, float2 Xb, float &ma, float &pa, float &mb, float &pb)
+VOC_DEV void polar_pair(float2 Xa, float2 Xb, float scale, float &ma, float &pa, float &mb, float &pb)
 {
     if (VOC_F32_PACKED) {
-        hs_polar_pair(Xa.x, Xa.y, Xb.x, Xb.y, ma, pa, mb, pb);
+        hs_polar_pair(Xa.x, Xa.y, Xb.x, Xb.y, scale, ma, pa, mb, pb);
     } else {
         hs_polar<LEAN>(Xa.x, Xa.y, ma, pa);
         hs_polar<LEAN>(Xb.x, Xb.y, mb, pb);
+        ma *= scale;
+        mb *= scale;
+    }
+}
+VOC_DEV double bins_ft(const PairBinsT<double> &) { return 0.0; }
+VOC_DEV float bins_ft(const PairBinsT<float> &b) { return b.ft; }
+// (fa: the first bin number as a float, float kernels only; ka + kb = M)
+VOC_DEV void inc_pow2_pair(const ParamsT<double> &p, const PairBinsT<double> &, double, int, int ka, int kb, double da, double db, double &ia, double &ib)
+{
+    ia = phase_inc_pow2(p, ka, da);
+    ib = phase_inc_pow2(p, kb, db);
+}
+VOC_DEV void inc_pow2_pair(const ParamsT<float> &p, const PairBinsT<float> &bins, float fa, int M, int ka, int kb, float da, float db, float &ia, float &ib)
+{
+    if (VOC_F32_PACKED) {
+        const f32x2 kf = fma2(splat2(fa), pk2(1.0f, -1.0f), pk2(0.0f, (float)M));
+        phase_inc_pow2_pair_kf(p, kf, bins.kmhi, da, db, ia, ib);
+    } else {
+        ia = phase_inc_pow2(p, ka, da);
+        ib = phase_inc_pow2(p, kb, db);
     }
 }
 VOC_DEV void inc_pow2_pair(const ParamsT<double> &p, int ka, int kb, double da, double db, double &ia, double &ib)

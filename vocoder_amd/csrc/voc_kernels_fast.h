@@ -823,6 +823,8 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
         const int lt = opaque_int(tid);
         const bool self0 = lt == 0;
         const unsigned pe0 = self0 ? M / 2 : (unsigned)lt;      // first pair: bins pe0 and M - pe0
+        PairBinsT<R> bins;
+        if constexpr (SLIDE > 0) bins.frame(p, lt);
         const C2 *zlo = lds + lds_sw(lt), *zhi = lds + lds_sw(M - lt);
         if constexpr (KEEP) {
             __syncthreads();  // the last pass' input has been read by everyone
@@ -869,13 +871,13 @@ __global__ void __launch_bounds__(FastCfg<LOG2M>::T, VOC_FAST_WAVES) analysis_fa
                 pb = at_bytes(php, oq, iq);
             }
             R ma, mb, pha, phb;
-            polar_pair<VOC_POLAR_LEAN != 0>(Xa, Xb, ma, pha, mb, phb);
+            polar_pair<VOC_POLAR_LEAN != 0>(Xa, Xb, half_vol, ma, pha, mb, phb);
             if (emit) {
-                at_bytes(mrow, ope, ipe) = ma * half_vol;
-                at_bytes(mrow, oq, iq) = mb * half_vol;
+                at_bytes(mrow, ope, ipe) = ma;
+                at_bytes(mrow, oq, iq) = mb;
                 if constexpr (SLIDE > 0) {  // H = SLIDE * N/8: a power of two, like N
                     R ia, ib;
-                    inc_pow2_pair(p, (int)pe, (int)q, pha - pa, phb - pb, ia, ib);
+                    inc_pow2_pair(p, bins, m == 0 ? (self0 ? (R)(M / 2) : bins_ft(bins)) : bins_ft(bins) + (R)(m * T), M, (int)pe, (int)q, pha - pa, phb - pb, ia, ib);
                     at_bytes(irow, ope, ipe) = ia;
                     at_bytes(irow, oq, iq) = ib;
                 } else {

@@ -415,6 +415,8 @@ __global__ void __launch_bounds__(Fast16Cfg<LOG2M>::T, (fast16_waves<R, LOG2M>(2
         const int lt = opaque_int(tid);
         const bool self0 = lt == 0;
         const unsigned pe0 = self0 ? M / 2 : (unsigned)lt;
+        PairBinsT<R> bins;
+        if constexpr (SLIDE > 0) bins.frame(p, lt);
         __syncthreads();  // the last pass' input has been read by everyone
         mark(10);
         {
@@ -454,13 +456,13 @@ __global__ void __launch_bounds__(Fast16Cfg<LOG2M>::T, (fast16_waves<R, LOG2M>(2
             C2 Xa, Xb;
             split_pair_x2(P, Q, w, Xa, Xb);
             R ma, mb, na, nb;
-            polar_pair<VOC_POLAR_LEAN != 0>(Xa, Xb, ma, na, mb, nb);
+            polar_pair<VOC_POLAR_LEAN != 0>(Xa, Xb, half_vol, ma, na, mb, nb);
             if (emit) {
-                at_bytes(mrow, ope, ipe) = ma * half_vol;
-                at_bytes(mrow, oq, iq) = mb * half_vol;
+                at_bytes(mrow, ope, ipe) = ma;
+                at_bytes(mrow, oq, iq) = mb;
                 if constexpr (SLIDE > 0) {  // H = SLIDE * N/16: a power of two, like N
                     R ia, ib;
-                    inc_pow2_pair(p, (int)pe, (int)q, na - pha[m], nb - phb[m], ia, ib);
+                    inc_pow2_pair(p, bins, m == 0 ? (self0 ? (R)(M / 2) : bins_ft(bins)) : bins_ft(bins) + (R)(m * T), M, (int)pe, (int)q, na - pha[m], nb - phb[m], ia, ib);
                     at_bytes(irow, ope, ipe) = ia;
                     at_bytes(irow, oq, iq) = ib;
                 } else {
