@@ -10,7 +10,8 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 H = N // 4
 F = (2880000 - N) // H + 1
 win = 0.5 * (1 - np.cos(2 * np.pi * np.arange(N) / N))
-par = V.VocoderParams(N, H, win)
+from vocoder_amd._ffi import Library
+par = V.VocoderParams(N, H, win, lib=Library(os.environ['VOC_LIB']) if os.environ.get('VOC_LIB') else None)   # development: time an experimental build
 ldk = (par.K + 1) & ~1
 mag = torch.rand((C_, F, ldk), dtype=torch.float64, device="cuda")
 inc = torch.rand_like(mag)

@@ -96,6 +96,33 @@ VOC_DEV double convolve_fast_at(const double *mag, int K, const double *ker, int
     return acc;
 }
 
+// log(x) for a positive normal x (the envelope takes it of a modulus plus 2^-24): the classical reduction
+// x = 2^k m, sqrt(1/2) <= m < sqrt(2), f = m - 1, s = f / (2 + f), log(m) = f - (f^2/2 - s (f^2/2 + R(s^2)))
+// with the degree-14 even polynomial R of fdlibm's e_log.c (public coefficients; error below 1 ulp), without the
+// device library's tests for zero, negative, infinite and subnormal arguments: 40 instructions where its log has 95.
+VOC_DEV double log_pos(double x)
+{
+#ifdef VOC_EMU
+    int k;
+    double m = frexp(x, &k);
+#else
+    int k = __builtin_amdgcn_frexp_exp(x);
+    double m = __builtin_amdgcn_frexp_mant(x);
+#endif
+    const bool low = m < 0.70710678118654752440;   // m in [1/2, 1): bring it into [sqrt(1/2), sqrt(2))
+    m = low ? m + m : m;
+    k = low ? k - 1 : k;
+    const double f = m - 1.0;
+    const double s = div_pos<false>(f, 2.0 + f);
+    const double dk = (double)k;
+    const double z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+}
+
 // rows too long for two staging arrays in LDS
 constexpr bool filter_one_array(int log2m) { return log2m >= 14; }
 
@@ -210,7 +237,7 @@ __global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p
 #pragma unroll
                     for (int j = 0; j < NE; ++j) {
                         const int k = tid + T * j;
-                        if (k < K) lm[h + k] = log(m[j] + ee);
+                        if (k < K) lm[h + k] = log_pos(m[j] + ee);
                     }
                     for (int i = tid; i < op.len; i += T) lm[i < h ? i : K + i] = 0.0;  // h in front, len - h behind
                     __syncthreads();
@@ -238,7 +265,7 @@ __global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
                     const int k = tid + T * j;
-                    if (k < K) lm[k] = log(m[j] + ee);
+                    if (k < K) lm[k] = log_pos(m[j] + ee);
                 }
                 __syncthreads();
 #pragma unroll
