@@ -64,6 +64,34 @@ def test_f32_every_specialised_length_and_hop(gpu_lib, orc, n, ratio):
         assert err <= TOL_F32_L2, (i, err)
 
 
+@pytest.mark.parametrize("n,hop", [(1024, 256), (1024, 100), (2048, 512), (4096, 1024), (4096, 1000), (8192, 2048), (16384, 4096)])
+def test_f32_stage_level_every_specialised_length(gpu_lib, n, hop):
+    """analysisStage / synthesisStage on float (the builds that take frames in and hand frames out) against the
+    double-precision stages of the same library: magnitudes, increments and frames of every channel."""
+    from vocoder_amd import vocoder as V
+    win = _hann(n)
+    p32 = V.VocoderParams(n, hop, win, lib=gpu_lib, precision="f32")
+    p64 = V.VocoderParams(n, hop, win, lib=gpu_lib)
+    rng = np.random.default_rng(n + hop)
+    c, f = 2, 7
+    frames = rng.standard_normal((c, f, n))
+    ph0 = rng.uniform(-3, 3, (c, p64.K))
+    ph64, (m64, i64) = V.analysis_stage(p64, ph0, frames)
+    ph32, (m32, i32) = V.analysis_stage(p32, ph0.astype(np.float32), frames.astype(np.float32))
+    assert m32.dtype == np.float32
+    scale = np.abs(m64).max()
+    assert np.abs(m32 - m64).max() <= 2e-6 * scale
+    strong = m64 >= 1e-3 * scale                      # phases of bins that carry signal
+    d = np.angle(np.exp(1j * (ph32.astype(np.float64) - ph64)))
+    assert np.abs(d[strong[:, -1, :]]).max() <= 1e-3
+    s64, y64 = V.synthesis_stage(p64, ph0, (m64, i64))
+    s32, y32 = V.synthesis_stage(p32, ph0.astype(np.float32), (m64.astype(np.float32), i64.astype(np.float32)))
+    assert y32.dtype == np.float32 and np.isfinite(y32).all()
+    for ch in range(c):
+        err = np.linalg.norm(y32[ch] - y64[ch]) / np.linalg.norm(y64[ch])
+        assert err <= 5e-4, (ch, err)
+
+
 @pytest.mark.parametrize("n,w,hop", [(4096, 4096, 1024), (2048, 1500, 512), (256, 256, 64)])
 def test_f32_stage_signal_filter_and_stream_forms_on_device(gpu_lib, orc, n, w, hop):
     """The single-precision forms beyond the fused call: stages against the double-precision oracle to the variant's
