@@ -64,6 +64,25 @@ def test_f32_every_specialised_length_and_hop(gpu_lib, orc, n, ratio):
         assert err <= TOL_F32_L2, (i, err)
 
 
+@pytest.mark.parametrize("scale", [32768.0, 1e-6, 1e12, 1e-12])
+def test_f32_input_scale(gpu_lib, orc, scale):
+    """The float kernels square the components of a bin without prescaling: samples on the 16-bit integer scale, far
+    below it and absurdly far on either side keep the variant's bar (a bin needs 1e-19 < |X| < 1e19)."""
+    from vocoder_amd import vocoder as V, conduit as Cd
+    n, hop = 4096, 1024
+    win = _hann(n)
+    p32 = V.VocoderParams(n, hop, win, lib=gpu_lib, precision="f32")
+    rng = np.random.default_rng(5)
+    length = n + hop * 30 + 3
+    t = np.arange(length)
+    x = scale * (0.5 * np.sin(2 * np.pi * 0.0071 * t) + 0.25 * np.sin(2 * np.pi * 0.13 * t + 1) + 0.01 * rng.uniform(-1, 1, length))
+    xf = x.astype(np.float32)[None, :]
+    y, left, (aph, sph) = Cd.process_with(p32, xf)
+    ref = orc.roundtrip(n, hop, win, xf[0].astype(np.float64), hop)
+    err = np.linalg.norm(y[0] - ref["y"]) / np.linalg.norm(ref["y"])
+    assert np.isfinite(y).all() and err <= TOL_F32_L2, err
+
+
 @pytest.mark.parametrize("n,hop", [(1024, 256), (1024, 100), (2048, 512), (4096, 1024), (4096, 1000), (8192, 2048), (16384, 4096)])
 def test_f32_stage_level_every_specialised_length(gpu_lib, n, hop):
     """analysisStage / synthesisStage on float (the builds that take frames in and hand frames out) against the
