@@ -139,8 +139,16 @@ struct FiltCfg {
 // 16384 -- have room for one array only and stage the moduli and the increments one after the other).
 // S: the type the STFT is stored in.  The arithmetic is the reference's, in double, whatever S is: a float
 // STFT (single-precision contexts) is widened on load and rounded once on store.
-template <int LOG2M, class S = double>
-__global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p, FilterProg prog,
+// ONLY >= 0: a build for chains made of that one kind of operation.  The registers of the kernel are those of its
+// hungriest case (240: two waves per SIMD); the envelope alone fits three (166 registers, none spilled) and gains a
+// sixth from the third (3.6 -> 3.0 ms per 180 k rows of 2049 bins).
+template <int ONLY>
+constexpr int filter_min_waves()  // waves per SIMD the build is made for (registers per thread: 512 / that)
+{
+    return ONLY == FOP_ENVELOPE ? 3 : 1;
+}
+template <int LOG2M, class S = double, int ONLY = -1>
+__global__ __launch_bounds__(FiltCfg<LOG2M>::T, (filter_min_waves<ONLY>())) void filter_rows_kernel(Params p, FilterProg prog,
                                                                         S *__restrict__ mag,
                                                                         S *__restrict__ inc, long long ldk,
                                                                         long long rows, long long F, long long rpc,
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(FiltCfg<LOG2M>::T) void filter_rows_kernel(Params p
         }
         for (int o = 0; o < prog.n; ++o) {
             const FilterOp op = prog.op[o];
-            switch (op.kind) {
+            switch (ONLY >= 0 ? ONLY : op.kind) {
             case FOP_GAIN:  // linearAmplitudeFilter (Filter.hs:76-77): mag * gain, phase increments kept
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
