@@ -145,7 +145,7 @@ struct FiltCfg {
 template <int ONLY>
 constexpr int filter_min_waves()  // waves per SIMD the build is made for (registers per thread: 512 / that)
 {
-    return ONLY == FOP_ENVELOPE ? 3 : (ONLY == FOP_RANDOM_PHASE ? 4 : 1);
+    return ONLY == FOP_ENVELOPE ? 3 : ((ONLY == FOP_RANDOM_PHASE || ONLY == FOP_GAIN) ? 4 : 1);
 }
 template <int LOG2M, class S = double, int ONLY = -1>
 __global__ __launch_bounds__(FiltCfg<LOG2M>::T, (filter_min_waves<ONLY>())) void filter_rows_kernel(Params p, FilterProg prog,
